@@ -1,0 +1,223 @@
+"""CPU oracle for the weight quantize -> dequantize -> error path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+cpu_baseline leg -- never by the quantization_amd package.
+
+Two halves:
+  * the quantize half binds oracle/libmq_oracle.so (mq_oracle.c, a C restatement of
+    /root/reference/quant_utils/quant_weight.py :229-335, :503-601, :717-872);
+  * the error half restates, in numpy, the arithmetic of the reference's analysis scripts
+    (they are plain numpy themselves, so this half is the same library calls in the same order):
+      MSE&P99/quant_error_multi_weight.py   :35-38, :55-87
+      MSE&P99/quant_error_single_weight.py  :46-79
+      elwise_error/onnx_error_cli.py        :90-127
+      elwise_error/single_weight_quant_error.py :39-52
+      elwise_error/compare.py               :99-143
+
+Parity status: pinned by tests/golden/*.npz, generated from the imported reference by
+tests/golden/gen_golden.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+F16, BF16, F32 = 0, 1, 2
+INT_SYM, INT_ASYM, LUT = 0, 1, 2
+
+# (exponent bits, mantissa bits, bias) of the LUT formats on the hot path
+LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3)}
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("fmt", ctypes.c_int32), ("bits", ctypes.c_int32), ("ebits", ctypes.c_int32),
+                ("mbits", ctypes.c_int32), ("bias", ctypes.c_int32), ("lut_f32_path", ctypes.c_int32),
+                ("group_size", ctypes.c_int64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libmq_oracle.so")
+    src = os.path.join(_HERE, "mq_oracle.c")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libmq_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libmq_oracle.so")
+        if not os.path.exists(so):
+            so = build()
+        L = ctypes.CDLL(so)
+        vp, i64 = ctypes.c_void_p, ctypes.c_int64
+        L.orc_quantize.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.POINTER(_Cfg), vp, vp, vp, vp, vp]
+        L.orc_quantize.restype = ctypes.c_int
+        L.orc_quantize_rows_mt.argtypes = L.orc_quantize.argtypes + [ctypes.c_int]
+        L.orc_quantize_rows_mt.restype = ctypes.c_int
+        L.orc_lut_round_f16.argtypes = [ctypes.c_uint16, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.orc_lut_round_f16.restype = ctypes.c_uint16
+        L.orc_f2h.argtypes = [ctypes.c_float]
+        L.orc_f2h.restype = ctypes.c_uint16
+        L.orc_h2f.argtypes = [ctypes.c_uint16]
+        L.orc_h2f.restype = ctypes.c_float
+        L.orc_build_lut.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
+        L.orc_build_lut.restype = ctypes.c_int
+        _LIB = L
+    return _LIB
+
+
+def build_lut(ebits, mbits, bias):
+    out = np.zeros(1024, np.float64)
+    n = lib().orc_build_lut(ebits, mbits, bias, out.ctypes.data, 1024)
+    return out[:n].copy()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def quantize(w, dtype, fmt, bits=8, group_size=None, datatype=None, lut_f32_path=False, nthreads=1,
+             want=("v16", "deq", "q", "scale", "zp")):
+    """w: 2-D numpy array; float16 / float32 directly, bfloat16 as a uint16 bit array with dtype=BF16.
+
+    Returns a dict of numpy arrays: v16/deq (uint16 float16 bits, [K,C]), q ([K,C] uint8 for INT
+    formats -- reinterpret as int8 where the reference returns int8 -- or uint16 float16 bits for LUT
+    formats), scale / zp (uint16 float16 bits, [nseg]).
+    """
+    assert w.ndim == 2 and w.flags.c_contiguous
+    K, C = w.shape
+    gs = 0 if group_size is None else int(group_size)
+    if gs < -1:
+        gs = 0
+    cfg = _Cfg(fmt=fmt, bits=bits, group_size=gs, lut_f32_path=int(bool(lut_f32_path)))
+    if fmt == LUT:
+        cfg.ebits, cfg.mbits, cfg.bias = LUT_FORMATS[datatype]
+    n = K * C
+    L = n if gs == -1 else (C if gs <= 0 else gs)
+    nseg = n // L if L else 0
+    out = {}
+    if "v16" in want:
+        out["v16"] = np.empty((K, C), np.uint16)
+    if "deq" in want:
+        out["deq"] = np.empty((K, C), np.uint16)
+    if "q" in want:
+        out["q"] = np.empty((K, C), np.uint16 if fmt == LUT else np.uint8)
+    if "scale" in want:
+        out["scale"] = np.empty(nseg, np.uint16)
+    if "zp" in want and fmt == INT_ASYM:
+        out["zp"] = np.empty(nseg, np.uint16)
+    rc = lib().orc_quantize_rows_mt(w.ctypes.data, dtype, K, C, ctypes.byref(cfg), _ptr(out.get("v16")),
+                                    _ptr(out.get("deq")), _ptr(out.get("q")), _ptr(out.get("scale")),
+                                    _ptr(out.get("zp")), int(nthreads))
+    if rc == -2:
+        raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {n}")
+    if rc:
+        raise ValueError(f"oracle: bad argument (rc={rc})")
+    return out
+
+
+# --------------------------------------------------------------------------- error half (numpy)
+
+def proto_to_array(raw):
+    """quant_error_multi_weight.py:35-38 -- initializer values widened to float32."""
+    return np.asarray(raw).astype(np.float32)
+
+
+def compute_mse(a, b):
+    """quant_error_multi_weight.py:55-58 (the single-weight twin :46-48 gets float32 inputs already)."""
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    diff = a32 - b32
+    return float(np.mean(diff * diff))
+
+
+def compute_errors_multi(a, b, grouping, gs):
+    """quant_error_multi_weight.py:61-87 -- per-COLUMN / per-column-block vectors."""
+    result = {"mse_tensor": compute_mse(a, b)}
+    per_vec = None
+    if grouping == "per-channel" and a.ndim == 2:
+        _, C = a.shape
+        per_vec = [compute_mse(a[:, c], b[:, c]) for c in range(C)]
+    elif grouping == "per-group" and a.ndim == 2:
+        _, C = a.shape
+        assert gs and C % gs == 0, "group size mismatch"
+        per_vec = [compute_mse(a[:, g * gs:(g + 1) * gs], b[:, g * gs:(g + 1) * gs]) for g in range(C // gs)]
+    if per_vec is not None:
+        vec = np.array(per_vec)
+        result.update({"per_vec": vec, "mse_rep": float(vec.mean()), "mse_p99": float(np.percentile(vec, 99))})
+    return result
+
+
+def compute_errors_single(a, b, grouping, gs):
+    """quant_error_single_weight.py:50-79 -- per-ROW / per-(row, group) vectors, row-major order."""
+    result = {"mse_tensor": compute_mse(a, b)}
+    per_vec = None
+    if grouping == "per-channel" and a.ndim == 2:
+        K, _ = a.shape
+        per_vec = [compute_mse(a[k, :], b[k, :]) for k in range(K)]
+    elif grouping == "per-group" and a.ndim == 2:
+        K, C = a.shape
+        assert gs and C % gs == 0, "group size mismatch"
+        G = C // gs
+        a3, b3 = a.reshape(K * G, gs), b.reshape(K * G, gs)
+        per_vec = [compute_mse(a3[i], b3[i]) for i in range(K * G)]
+    if per_vec is not None:
+        vec = np.array(per_vec)
+        result.update({"per_vec": vec, "mse_rep": float(vec.mean()), "mse_p99": float(np.percentile(vec, 99))})
+    return result
+
+
+def elementwise_f32(w_fp16, w_q):
+    """onnx_error_cli.py:90-91, :113-117 -- float32 error, abs, P99, sum."""
+    e = (w_fp16.astype(np.float32) - w_q.astype(np.float32)).flatten()
+    a = np.abs(e)
+    return {"err": e, "abs": a, "p99": np.percentile(a, 99), "sum": np.sum(a)}
+
+
+def sliced_stats(err, start, end):
+    """onnx_error_cli.py:97-103, :119-127."""
+    end = min(end, err.size)
+    s = err[start:end]
+    return {"mse": np.mean(np.square(s)), "abs_sum": np.sum(np.abs(s))}
+
+
+def bucketize(w_fp16, w_q, step=0.0001, max_value=0.0007):
+    """single_weight_quant_error.py:39-52 -- float16 error, bucket index and bucket value."""
+    err = (w_fp16 - w_q).flatten()
+    abs_err = np.abs(err)
+    bins = np.arange(step, max_value + step, step)
+    values = np.arange(len(bins)) * step
+    idx = np.digitize(abs_err, bins, right=True)
+    idx = np.minimum(idx, len(values) - 1)
+    return {"abs_err": abs_err, "bins": bins, "idx": idx, "values": values[idx]}
+
+
+def compare_formats(w_fp16, w_qs, threshold=0.02):
+    """compare.py:99-125 -- w_qs: list of float16 arrays, one per format."""
+    w = w_fp16.flatten()
+    all_err = np.stack([np.abs(w - q.flatten()) for q in w_qs], axis=0)
+    min_err = all_err.min(axis=0)
+    mask_out = min_err > threshold
+    best = [(all_err[i] == min_err) & ~mask_out for i in range(len(w_qs))]
+    return {"all_err": all_err, "min_err": min_err, "mask_out": mask_out, "best": best}
+
+
+def to_ranges(idx_array):
+    """compare.py:130-143 -- run-length (start, length) pairs of a sorted index list."""
+    idx = np.sort(idx_array)
+    if idx.size == 0:
+        return []
+    ranges = []
+    start = prev = idx[0]
+    for x in idx[1:]:
+        if x == prev + 1:
+            prev = x
+        else:
+            ranges.append((int(start), int(prev - start + 1)))
+            start = prev = x
+    ranges.append((int(start), int(prev - start + 1)))
+    return ranges

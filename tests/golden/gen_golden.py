@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by IMPORTING the reference
+(/root/reference/quant_utils/quant_weight.py) in the build container.
+
+Run once, by hand, where /root/reference exists:  python tests/golden/gen_golden.py
+The GPU box has no /root/reference; tests only read the .npz / .json files written here.
+
+Files written:
+  quant_small.npz       inputs (several distributions x input dtypes) and, for every
+                        format x group size, the reference's deq / codes / scale / zero-point bits
+  quant_exhaustive.npz  all 65 536 float16 bit patterns as one 256x256 matrix (non-finite ones
+                        replaced by 0) and the reference outputs for per-channel / g=128
+  lut_domain.npz        x-domain sweep of the LUT rounding: rows whose scale is exactly 1
+  lut_tables.json       the reference's FP8_E4M3 / FP8_E3M4 value lists
+  error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
+                        arithmetic on seeded 512x1024 inputs (scalars and digests only)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from quant_utils import quant_weight as qw  # noqa: E402  (the reference)
+
+from oracle import oracle as orc  # noqa: E402  (numpy restatement of the analysis scripts)
+
+FORMATS = ["int8", "int8_asym", "fp8_e4m3", "fp8_e3m4"]
+GROUPS = [None, 32, 64, 128, -1]
+
+
+def gs_key(gs):
+    return "none" if gs is None else str(gs)
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def run_reference(w, fmt, gs):
+    """-> dict of numpy bit arrays exactly as the reference returns them."""
+    out = {}
+    if fmt.startswith("int"):
+        asym = "asym" in fmt
+        d, q, s, zp = qw._int_quant_meta(w, wq_bits=8, asym=asym, group_size=gs)
+        d2 = (qw.quant_int_asym if asym else qw.quant_int)(w, wq_bits=8, group_size=gs)
+        assert torch.equal(bits_t(d), bits_t(d2.reshape_as(d)))
+        out["deq"] = bits16(d)
+        out["q"] = q.contiguous().view(torch.uint8).numpy().copy()
+        out["q_is_int8"] = np.array(q.dtype == torch.int8)
+        out["scale"] = bits16(s.reshape(-1))
+        if zp is not None:
+            out["zp"] = bits16(zp.reshape(-1))
+    else:
+        d, q, s = qw._fp_quant_meta(w, wq_bits=8, datatype=fmt, group_size=gs)
+        out["deq"] = bits16(d)
+        out["q"] = bits16(q)
+        out["scale"] = bits16(s.reshape(-1))
+        # quant_datatype: same values, except the per-tensor branch which runs in float32
+        d2 = qw.quant_datatype(w, wq_bits=8, datatype=fmt, group_size=gs)
+        out["deq_quant_datatype"] = bits16(d2.reshape_as(d))
+    return out
+
+
+def bits_t(t):
+    return t.contiguous().view(torch.int16)
+
+
+def distributions(K, C, gen):
+    g = torch.randn(K, C, generator=gen)
+    yield "normal", g * 0.02
+    yield "heavy", g * 0.6
+    yield "tiny", g * 1e-6
+    yield "allpos", 1 + torch.rand(K, C, generator=gen) * 1e-3
+    o = g * 0.02
+    o[:, 3] = 60000.0
+    yield "outlier", o
+    z = g * 0.02
+    z[1] = 0
+    z[2, : C // 2] = 0
+    z[3, 5] = -0.0
+    yield "zerorows", z
+    yield "relu", torch.relu(g) * 0.05
+    yield "big", g * 3000
+    t = torch.distributions.StudentT(3.0).sample((K, C)) * 0.02
+    yield "student_t", t
+
+
+def gen_quant_small():
+    gen = torch.Generator().manual_seed(0)
+    torch.manual_seed(0)
+    K, C = 8, 512
+    arrays = {}
+    for name, w in distributions(K, C, gen):
+        variants = [("f16", w.half())]
+        if name in ("normal", "heavy", "big"):
+            variants += [("bf16", w.bfloat16()), ("f32", w.float())]
+        for dt, wt in variants:
+            key = f"{name}.{dt}"
+            arrays[f"in/{key}"] = wt.numpy().copy() if dt == "f32" else bits16(wt)
+            for fmt in FORMATS:
+                for gs in GROUPS:
+                    for k, v in run_reference(wt, fmt, gs).items():
+                        arrays[f"out/{key}/{fmt}/{gs_key(gs)}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "quant_small.npz"), **arrays)
+    print("quant_small.npz", len(arrays), "arrays")
+
+
+def gen_exhaustive():
+    bits = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    w = torch.from_numpy(bits.view(np.int16).copy()).view(torch.float16)
+    w = torch.where(torch.isfinite(w), w, torch.zeros_like(w))
+    arrays = {"in": bits16(w)}
+    for fmt in FORMATS:
+        for gs in [None, 128]:
+            for k, v in run_reference(w, fmt, gs).items():
+                arrays[f"out/{fmt}/{gs_key(gs)}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "quant_exhaustive.npz"), **arrays)
+    print("quant_exhaustive.npz", len(arrays), "arrays")
+
+
+def gen_lut_domain():
+    """Rows padded with +-LUTmax so that scale == 1 and x == the element itself: every float16
+    pattern with |x| <= LUTmax goes through the reference's LUT rounding."""
+    arrays = {}
+    for fmt, lutmax in (("fp8_e4m3", 480.0), ("fp8_e3m4", 31.0)):
+        allv = torch.from_numpy(np.arange(65536, dtype=np.uint16).view(np.int16).copy()).view(torch.float16)
+        keep = allv[torch.isfinite(allv) & (allv.abs() <= lutmax)]
+        C = 1024
+        rows = (keep.numel() + C - 2) // (C - 1)
+        w = torch.zeros(rows, C, dtype=torch.float16)
+        w[:, 0] = lutmax
+        flat = torch.zeros(rows * (C - 1), dtype=torch.float16)
+        flat[: keep.numel()] = keep
+        w[:, 1:] = flat.reshape(rows, C - 1)
+        d, q, s = qw._fp_quant_meta(w, wq_bits=8, datatype=fmt, group_size=None)
+        assert torch.all(s == 1.0)
+        arrays[f"{fmt}/in"] = bits16(w)
+        arrays[f"{fmt}/q"] = bits16(q)
+        arrays[f"{fmt}/deq"] = bits16(d)
+    np.savez_compressed(os.path.join(HERE, "lut_domain.npz"), **arrays)
+    print("lut_domain.npz")
+
+
+def gen_lut_tables():
+    with open(os.path.join(HERE, "lut_tables.json"), "w") as f:
+        json.dump({k: list(map(float, qw.DATATYPE_MAPPING_8_BIT[k])) for k in ("fp8_e4m3", "fp8_e3m4")}, f)
+    print("lut_tables.json")
+
+
+def digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def gen_error_stats():
+    """Known answers for the error half.  Inputs come from numpy's PCG64 stream so the tests can
+    regenerate them; the quantized tensors come from the imported reference; the statistics are the
+    analysis scripts' numpy expressions (restated in oracle/oracle.py -- those scripts need the
+    `onnx` package to import, which this image does not have)."""
+    K, C = 512, 1024
+    rng = np.random.default_rng(1)
+    cases = {"normal": (rng.standard_normal((K, C)) * 0.02).astype(np.float16),
+             "student_t": (rng.standard_t(3, (K, C)) * 0.02).astype(np.float16)}
+    res = {"K": K, "C": C, "seed": 1, "cases": {}}
+    for cname, w16 in cases.items():
+        w = torch.from_numpy(w16)
+        res["cases"][cname] = {"input_sha256": digest(w16), "formats": {}}
+        for fmt in FORMATS:
+            for gs in [None, 32, 64, 128]:
+                ref = run_reference(w, fmt, gs)
+                deq = ref["deq"].view(np.float16).reshape(K, C)
+                a32, b32 = orc.proto_to_array(w16), orc.proto_to_array(deq)
+                grouping = "per-channel" if gs is None else "per-group"
+                multi = orc.compute_errors_multi(a32, b32, grouping, gs)
+                single = orc.compute_errors_single(a32, b32, grouping, gs)
+                el = orc.elementwise_f32(w16, deq)
+                sl = orc.sliced_stats(el["err"], 1000, 200000)
+                bk = orc.bucketize(w16, deq)
+                entry = {
+                    "deq_sha256": digest(ref["deq"]), "q_sha256": digest(ref["q"]),
+                    "scale_sha256": digest(ref["scale"]),
+                    "mse_tensor": multi["mse_tensor"],
+                    "multi": {"mse_rep": multi["mse_rep"], "mse_p99": multi["mse_p99"],
+                              "per_vec_sha256": digest(multi["per_vec"])},
+                    "single": {"mse_rep": single["mse_rep"], "mse_p99": single["mse_p99"],
+                               "per_vec_sha256": digest(single["per_vec"])},
+                    "abs_p99_f32_bits": int(np.float32(el["p99"]).view(np.uint32)),
+                    "abs_sum_f32_bits": int(np.float32(el["sum"]).view(np.uint32)),
+                    "abs_sha256": digest(el["abs"]),
+                    "sliced_mse_f32_bits": int(np.float32(sl["mse"]).view(np.uint32)),
+                    "sliced_abs_sum_f32_bits": int(np.float32(sl["abs_sum"]).view(np.uint32)),
+                    "bucket_idx_sha256": digest(bk["idx"].astype(np.int64)),
+                    "abs_f16_sha256": digest(bk["abs_err"]),
+                }
+                if "zp" in ref:
+                    entry["zp_sha256"] = digest(ref["zp"])
+                res["cases"][cname]["formats"][f"{fmt}/{gs_key(gs)}"] = entry
+        # compare.py on the three 8-bit formats, per-channel
+        qs = [run_reference(w, f, None)["deq"].view(np.float16).reshape(K, C) for f in ("int8", "fp8_e4m3", "fp8_e3m4")]
+        cmp_ = orc.compare_formats(w16, qs, threshold=0.02)
+        cmp_lo = orc.compare_formats(w16, qs, threshold=1e-4)
+        res["cases"][cname]["compare"] = {
+            "formats": ["int8", "fp8_e4m3", "fp8_e3m4"],
+            "min_err_sha256": digest(cmp_["min_err"]),
+            "thr_0.02": {"n_out": int(cmp_["mask_out"].sum()), "n_best": [int(b.sum()) for b in cmp_["best"]],
+                         "best_sha256": [digest(np.packbits(b)) for b in cmp_["best"]]},
+            "thr_1e-4": {"n_out": int(cmp_lo["mask_out"].sum()), "n_best": [int(b.sum()) for b in cmp_lo["best"]],
+                         "out_sha256": digest(np.packbits(cmp_lo["mask_out"])),
+                         "n_ranges_out": len(orc.to_ranges(np.where(cmp_lo["mask_out"])[0]))},
+        }
+    with open(os.path.join(HERE, "error_stats.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("error_stats.json")
+
+
+if __name__ == "__main__":
+    gen_lut_tables()
+    gen_quant_small()
+    gen_exhaustive()
+    gen_lut_domain()
+    gen_error_stats()

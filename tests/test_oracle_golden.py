@@ -1,0 +1,119 @@
+"""CPU: the C / numpy oracle against the golden vectors generated from the imported reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+
+def _fmt_args(orc, fmt):
+    if fmt == "int8":
+        return dict(fmt=orc.INT_SYM, bits=8)
+    if fmt == "int8_asym":
+        return dict(fmt=orc.INT_ASYM, bits=8)
+    return dict(fmt=orc.LUT, bits=8, datatype=fmt)
+
+
+def _dtype_code(orc, name):
+    return {"f16": orc.F16, "bf16": orc.BF16, "f32": orc.F32}[name]
+
+
+def _check(orc, w, dt, fmt, gs, exp):
+    K, C = w.shape
+    out = orc.quantize(w, _dtype_code(orc, dt), group_size=gs, **_fmt_args(orc, fmt))
+    assert np.array_equal(out["deq"], exp["deq"].reshape(K, C)), "deq bits"
+    assert np.array_equal(out["q"], exp["q"].reshape(K, C)), "codes"
+    assert np.array_equal(out["scale"], exp["scale"].reshape(-1)), "scale bits"
+    if "zp" in exp:
+        assert np.array_equal(out["zp"], exp["zp"].reshape(-1)), "zero-point bits"
+    if "deq_quant_datatype" in exp:
+        out2 = orc.quantize(w, _dtype_code(orc, dt), group_size=gs, lut_f32_path=(gs == -1),
+                            want=("deq",), **_fmt_args(orc, fmt))
+        assert np.array_equal(out2["deq"], exp["deq_quant_datatype"].reshape(K, C)), "quant_datatype deq"
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", gu.GROUPS, ids=gu.gs_key)
+def test_small_vectors(oracle, fmt, gs):
+    for key, dt, w in gu.small_inputs():
+        _check(oracle, w, dt, fmt, gs, gu.small_expected(key, fmt, gs))
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", [None, 128], ids=gu.gs_key)
+def test_exhaustive_f16_patterns(oracle, fmt, gs):
+    w, exp = gu.exhaustive_expected(fmt, gs)
+    _check(oracle, w, "f16", fmt, gs, exp)
+
+
+@pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp8_e3m4"])
+def test_lut_domain_sweep(oracle, fmt):
+    """Every float16 x with |x| <= LUTmax through the reference's LUT rounding (scale == 1)."""
+    z = gu.npz("lut_domain.npz")
+    w = z[f"{fmt}/in"]
+    out = oracle.quantize(w, oracle.F16, oracle.LUT, 8, None, datatype=fmt)
+    assert np.all(out["scale"] == 0x3C00)
+    assert np.array_equal(out["q"], z[f"{fmt}/q"].reshape(w.shape))
+    assert np.array_equal(out["deq"], z[f"{fmt}/deq"].reshape(w.shape))
+    e, m, b = oracle.LUT_FORMATS[fmt]
+    flat_in, flat_q = w.reshape(-1)[::37], out["q"].reshape(-1)[::37]
+    for x, q in zip(flat_in, flat_q):
+        assert oracle.lib().orc_lut_round_f16(int(x), e, m, b) == q
+
+
+def test_lut_tables_closed_form(oracle):
+    ref = gu.load_json("lut_tables.json")
+    for name, (e, m, b) in oracle.LUT_FORMATS.items():
+        assert np.array_equal(oracle.build_lut(e, m, b), np.array(ref[name]))
+
+
+def test_software_half_conversion(oracle):
+    L = oracle.lib()
+    bits = np.arange(65536, dtype=np.uint16)
+    f = bits.view(np.float16).astype(np.float32)
+    for b in range(0, 65536, 7):
+        x = L.orc_h2f(b)
+        if np.isnan(f[b]):
+            assert np.isnan(x)
+        else:
+            assert x == f[b] and np.signbit(x) == np.signbit(f[b])
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-7, 1e-4, 1, 300, 70000)])
+    xs = np.concatenate([xs, np.array([65504, 65519.99, 65520, 2 ** -24, 2 ** -25, 2 ** -25 * 1.0001, 0.0, -0.0,
+                                       np.inf, -np.inf], np.float32)])
+    want = xs.astype(np.float16).view(np.uint16)
+    for x, wv in zip(xs, want):
+        assert L.orc_f2h(float(x)) == wv
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_error_stats_known_answers(oracle):
+    """Quantize with the C oracle, run the numpy error half, compare with the stored known answers."""
+    gold = gu.load_json("error_stats.json")
+    K, C = gold["K"], gold["C"]
+    rng = np.random.default_rng(gold["seed"])
+    inputs = {"normal": (rng.standard_normal((K, C)) * 0.02).astype(np.float16),
+              "student_t": (rng.standard_t(3, (K, C)) * 0.02).astype(np.float16)}
+    for cname, w16 in inputs.items():
+        g = gold["cases"][cname]
+        assert _digest(w16) == g["input_sha256"], "numpy RNG stream changed; regenerate the golden file"
+        for key, e in g["formats"].items():
+            fmt, gk = key.split("/")
+            gs = None if gk == "none" else int(gk)
+            out = oracle.quantize(w16, oracle.F16, group_size=gs, **_fmt_args(oracle, fmt))
+            assert _digest(out["deq"]) == e["deq_sha256"]
+            assert _digest(out["q"]) == e["q_sha256"]
+            assert _digest(out["scale"]) == e["scale_sha256"]
+            if "zp_sha256" in e:
+                assert _digest(out["zp"]) == e["zp_sha256"]
+            if fmt == "int8_asym" and gs in (None, 64):
+                deq = out["deq"].view(np.float16)
+                grouping = "per-channel" if gs is None else "per-group"
+                m = oracle.compute_errors_multi(w16.astype(np.float32), deq.astype(np.float32), grouping, gs)
+                assert m["mse_tensor"] == e["mse_tensor"] and m["mse_p99"] == e["multi"]["mse_p99"]
+                el = oracle.elementwise_f32(w16, deq)
+                assert int(np.float32(el["p99"]).view(np.uint32)) == e["abs_p99_f32_bits"]
