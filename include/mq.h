@@ -1,0 +1,90 @@
+/*
+ * mq.h -- C ABI of libmq.so: MI355X (gfx950) kernels for the weight quantize -> dequantize -> error path.
+ *
+ * Plain C: raw device pointers, sizes, a HIP stream handle passed as void*.  No C++ or torch types.
+ * Every function enqueues on the caller's stream and returns without synchronising unless it says
+ * otherwise.  All buffers are allocated by the caller; the library keeps no pointer past the call and
+ * has no global mutable state.  Functions return MQ_OK (0) or a negative mq_status and never throw.
+ *
+ * "Reference" citations are into /root/reference (weirdmaverick/quantization).
+ */
+#ifndef MQ_H_
+#define MQ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2 } mq_dtype;
+
+/* Quantization formats of the hot path. */
+typedef enum {
+  MQ_INT_SYM = 0,  /* quant_int / _int_quant_meta(asym=False)      quant_weight.py:229-266, :768-775 */
+  MQ_INT_ASYM = 1, /* quant_int_asym / _int_quant_meta(asym=True)  quant_weight.py:298-335, :756-766 */
+  MQ_LUT_FP = 2    /* quant_datatype / _fp_quant_meta value tables quant_weight.py:503-601, :778-872 */
+} mq_format;
+
+typedef enum {
+  MQ_OK = 0,
+  MQ_ERR_ARG = -1,         /* null pointer, negative size, unknown enum            -> ValueError   */
+  MQ_ERR_GROUP = -2,       /* cols % group_size != 0                               -> RuntimeError */
+  MQ_ERR_UNSUPPORTED = -3, /* bit width / format outside the supported set         -> ValueError   */
+  MQ_ERR_WORKSPACE = -4,   /* workspace missing or smaller than mq_*_workspace_bytes               */
+  MQ_ERR_HIP = -5,         /* a HIP call failed (see mq_last_hip_error)                            */
+  MQ_ERR_ALIGN = -6        /* a pointer is not aligned to its element size                         */
+} mq_status;
+
+/* How to quantize.  group_size follows the reference: -1 per-tensor, any other value <= 0 per-channel
+ * (one segment per row), > 0 per-group (quant_weight.py:241-255). */
+typedef struct {
+  int32_t format;     /* mq_format */
+  int32_t bits;       /* INT formats: 2..8 */
+  int32_t exp_bits;   /* LUT formats: the value table is +-(1+m/2^M)*2^(e-bias) over all exponent codes, */
+  int32_t man_bits;   /*   no subnormals/inf/NaN, code (e=0,m=0) is the single zero:                      */
+  int32_t exp_bias;   /*   FP8_E4M3 = (4,3,7) quant_weight.py:114-138; FP8_E3M4 = (3,4,3) :91-113        */
+  int32_t f32_math;   /* 1 = quant_datatype's per-tensor float32 branch (quant_weight.py:562-575)        */
+  int64_t group_size;
+} mq_quant_cfg;
+
+/* Where to put results; any pointer may be NULL to skip that output.  nseg = number of segments
+ * (rows*cols/group, rows for per-channel, 1 for per-tensor). */
+typedef struct {
+  void* deq;             /* float16 [rows*cols]   dequantized weight (w_deq of _int_quant_meta/_fp_quant_meta) */
+  void* codes;           /* INT: 1 byte/element, low byte of the integer code (int8 or uint8 view,
+                            quant_weight.py:738,745,766,775); LUT: float16 table value (:870-872)  */
+  void* scale;           /* float16 [nseg] */
+  void* zero_point;      /* float16 [nseg], INT_ASYM only */
+  void* abs_err;         /* |float16(w) - deq| per element, float32 or float16 [rows*cols]          */
+  int32_t abs_err_dtype; /* MQ_F32: onnx_error_cli.py:90-91;  MQ_F16: single_weight_quant_error.py:39-40 */
+  int32_t reserved;
+  double* seg_sse;       /* float64 [nseg] sum of squared float32 errors per segment (row form,
+                            quant_error_single_weight.py:56-71 before the division by the length)  */
+  double* totals;        /* float64 [2]: sum of squared errors, sum of absolute errors (float32 errors,
+                            quant_error_multi_weight.py:55-58, onnx_error_cli.py:116-117)           */
+} mq_quant_out;
+
+int mq_version(void);
+const char* mq_strerror(int status);
+/* Text of the last HIP error seen by this thread ("" if none). */
+const char* mq_last_hip_error(void);
+
+/* Bytes of device workspace mq_quantize needs for this shape (reduction slots + per-block partials). */
+size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
+
+/*
+ * One fused pass over a row-major [rows, cols] weight: cast to float16, per-segment absmax or
+ * min/max, scale (and zero-point), quantize (round half to even), dequantize, error accumulation.
+ * Replaces quant_int :230, quant_int_asym :299, quant_datatype :504, _int_quant_meta :718 and
+ * _fp_quant_meta :779 of quant_weight.py, fused with the error arithmetic of
+ * MSE&P99/quant_error_multi_weight.py:55-58 and elwise_error/onnx_error_cli.py:90-91,:116-117.
+ */
+int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
+                const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MQ_H_ */

@@ -1,0 +1,125 @@
+"""Host side of the fused quantize -> dequantize -> error pass (one call = one mq_quantize launch).
+
+`quantize()` is the superset entry point; quantization_amd.quant_weight wraps it in the reference's
+function signatures.  Tensors stay on the ROCm device; nothing here synchronises with the host.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+# name -> (exp_bits, man_bits, bias) of the value-table formats
+# (reference: quant_weight.py FP8_E3M4 :91-113, FP8_E4M3 :114-138)
+LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3)}
+
+_DTYPES = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
+_workspaces = {}
+
+
+@dataclass
+class QuantResult:
+    rows: int
+    cols: int
+    nseg: int
+    deq: Optional[torch.Tensor] = None      # float16 [rows, cols]
+    codes: Optional[torch.Tensor] = None    # uint8 [rows, cols] (INT) or float16 [rows, cols] (LUT)
+    scale: Optional[torch.Tensor] = None    # float16 [nseg]
+    zero_point: Optional[torch.Tensor] = None
+    abs_err: Optional[torch.Tensor] = None  # float32 or float16 [rows, cols]
+    seg_sse: Optional[torch.Tensor] = None  # float64 [nseg]
+    totals: Optional[torch.Tensor] = None   # float64 [2]: sum err^2, sum |err|
+
+
+def require_device(t: torch.Tensor) -> torch.Tensor:
+    """ROCm tensors pass through; a host tensor is copied to the current ROCm device (there is no CPU
+    compute path)."""
+    if t.is_cuda:
+        return t
+    if not torch.cuda.is_available():
+        raise RuntimeError("quantization_amd needs a ROCm device (MI355X); no CPU fallback exists")
+    return t.cuda()
+
+
+def workspace(device, nbytes):
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws, stream
+
+
+def make_cfg(fmt, bits=8, group_size=None, datatype=None, f32_math=False):
+    gs = 0 if group_size is None else int(group_size)
+    if gs < -1:
+        gs = 0
+    cfg = _lib.QuantCfg(format=fmt, bits=int(bits), group_size=gs, f32_math=int(bool(f32_math)))
+    if fmt == _lib.LUT_FP:
+        cfg.exp_bits, cfg.man_bits, cfg.exp_bias = LUT_FORMATS[datatype]
+    return cfg
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+@torch.no_grad()
+def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
+             f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, totals=False,
+             out: Optional[QuantResult] = None) -> QuantResult:
+    """w: ROCm tensor viewed as [rows, cols] = [prod(shape[:-1]), shape[-1]], float16 / bfloat16 / float32.
+
+    abs_err: None, torch.float32 or torch.float16.  `out` may carry preallocated tensors to reuse.
+    """
+    if w.dtype not in _DTYPES:
+        raise ValueError(f"unsupported weight dtype {w.dtype}")
+    if not w.is_cuda:
+        raise RuntimeError("quantize() expects a ROCm device tensor")
+    cols = w.shape[-1] if w.dim() else 1
+    rows = w.numel() // cols if cols else 0
+    w2 = w.contiguous()
+    cfg = make_cfg(fmt, bits, group_size, datatype, f32_math)
+    gs = cfg.group_size
+    n = rows * cols
+    L = n if gs == -1 else (cols if gs <= 0 else gs)
+    if gs > 0 and cols % gs:
+        raise RuntimeError(f"shape '[{rows}, {cols // gs}, {gs}]' is invalid for input of size {n}")
+    nseg = n // L if L else 0
+    dev = w.device
+    res = out if out is not None else QuantResult(rows, cols, nseg)
+    res.rows, res.cols, res.nseg = rows, cols, nseg
+
+    def buf(cur, want, shape, dtype):
+        if not want:
+            return None
+        if cur is not None and cur.shape == torch.Size(shape) and cur.dtype == dtype and cur.device == dev:
+            return cur
+        return torch.empty(shape, dtype=dtype, device=dev)
+
+    res.deq = buf(res.deq, deq, (rows, cols), torch.float16)
+    res.codes = buf(res.codes, codes, (rows, cols), torch.float16 if fmt == _lib.LUT_FP else torch.uint8)
+    res.scale = buf(res.scale, scale, (nseg,), torch.float16)
+    res.zero_point = buf(res.zero_point, scale and fmt == _lib.INT_ASYM, (nseg,), torch.float16)
+    res.abs_err = buf(res.abs_err, abs_err is not None, (rows, cols), abs_err or torch.float32)
+    res.seg_sse = buf(res.seg_sse, seg_sse, (nseg,), torch.float64)
+    res.totals = buf(res.totals, totals, (2,), torch.float64)
+    if n == 0:
+        if res.totals is not None:
+            res.totals.zero_()
+        return res
+
+    L_ = _lib.lib()
+    o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale),
+                      zero_point=_ptr(res.zero_point), abs_err=_ptr(res.abs_err),
+                      abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
+                      seg_sse=_ptr(res.seg_sse), totals=_ptr(res.totals))
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L_.mq_quantize_workspace_bytes(rows, cols, ctypes.byref(cfg)))
+        st = L_.mq_quantize(w2.data_ptr(), _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ctypes.byref(o),
+                            ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return res

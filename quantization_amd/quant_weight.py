@@ -1,0 +1,199 @@
+"""Drop-in for the reference's quant_utils/quant_weight.py on the 8-bit hot path, running on MI355X.
+
+Same function names, argument meaning, return shapes/dtypes and exception types as the reference
+(citations are into /root/reference/quant_utils/quant_weight.py); the arithmetic runs in the fused HIP
+kernel behind include/mq.h.  A host tensor is moved to the current ROCm device and the result moved
+back, so the reference's CPU-tensor call sites keep working; there is no CPU compute path.
+
+Supported on the device: symmetric / asymmetric INT with 2..8 bits, and the value-table formats
+fp8_e4m3 and fp8_e3m4, each per-tensor (group_size == -1), per-channel (None / 0 / other negatives)
+or per-group (> 0).  Other table formats of the reference (fp3..fp6, flint, fp8_e2m5, fp8_e5m2, MX,
+mixed search) are not implemented and raise NotImplementedError.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .fused import LUT_FORMATS, quantize, require_device
+
+# names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
+# ValueError / AssertionError behaviour for unknown names
+_KNOWN_TABLES = {
+    3: {"int3", "fp3", "fp3_er_pos", "fp3_er_neg", "fp3_ea_pos", "fp3_ea_neg"},
+    4: {"int4", "fp4", "flint4", "fp4_er_pos", "fp4_er_neg", "fp4_ea_pos", "fp4_ea_neg"},
+    5: {"int5", "fp5", "flint5", "fp5_e2m2", "fp5_e3m1"},
+    6: {"int6", "fp6", "fp6_e2m3", "fp6_e3m2"},
+    8: {"int8", "fp8_e2m5", "fp8_e3m4", "fp8_e4m3", "fp8_e5m2"},
+}
+
+
+def _is_per_tensor(group_size):
+    return group_size == -1
+
+
+def _is_per_group(group_size):
+    return group_size is not None and group_size > 0
+
+
+def _run(w, fmt, bits, group_size, datatype=None, **kw):
+    """-> (QuantResult, original device).  Per-group needs a 2-D weight, as `K, C = w.size()` does
+    in the reference (quant_weight.py:252)."""
+    if _is_per_group(group_size):
+        K, C = w.size()  # raises ValueError for non 2-D input like the reference's unpacking
+    dev = w.device
+    res = quantize(require_device(w), fmt, bits, group_size, datatype, **kw)
+    return res, dev
+
+
+def _check_table(wq_bits, datatype):
+    if wq_bits not in _KNOWN_TABLES:
+        # quant_weight.py:552-554 / :790-791
+        raise ValueError(f"Currently only support 3-, 4-, 5-,6- and 8-bit quantization, not {wq_bits}-bit")
+    assert datatype in _KNOWN_TABLES[wq_bits], f"unexpected data type {datatype}."  # :556 / :793
+    if datatype not in LUT_FORMATS:
+        raise NotImplementedError(f"value-table format {datatype!r} has no MI355X kernel yet "
+                                  f"(supported: {sorted(LUT_FORMATS)})")
+
+
+@torch.no_grad()
+def quant_int(w_fp16, wq_bits: int = 4, group_size: Optional[int] = None):
+    """Symmetric INT fake-quantization; returns the dequantized float16 weight (quant_weight.py:229-266)."""
+    res, dev = _run(w_fp16, _lib.INT_SYM, wq_bits, group_size, codes=False, scale=False)
+    return res.deq.reshape(w_fp16.shape).to(dev)
+
+
+@torch.no_grad()
+def quant_int_asym(w_fp16, wq_bits: int = 4, group_size: Optional[int] = None):
+    """Asymmetric INT fake-quantization; returns the dequantized float16 weight (quant_weight.py:298-335)."""
+    res, dev = _run(w_fp16, _lib.INT_ASYM, wq_bits, group_size, codes=False, scale=False)
+    return res.deq.reshape(w_fp16.shape).to(dev)
+
+
+@torch.no_grad()
+def quant_datatype(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Optional[int] = None):
+    """Nearest-value quantization to a format's value table (quant_weight.py:503-601).  The per-tensor
+    branch computes in float32 as the reference does (:562-575)."""
+    _check_table(wq_bits, datatype)
+    res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype, f32_math=_is_per_tensor(group_size),
+                    codes=False, scale=False)
+    return res.deq.reshape(w_fp16.shape).to(dev)
+
+
+@torch.no_grad()
+def _int_quant_meta(w_fp16: torch.Tensor, wq_bits: int = 4, asym: bool = False, group_size: Optional[int] = None):
+    """(w_deq float16, q int8/uint8, scale float16, zp float16 | None) -- quant_weight.py:717-775.
+
+    Code dtype follows the reference: uint8 for asymmetric per-channel/per-group (:766) and for symmetric
+    per-tensor (:745), int8 for symmetric per-channel/per-group (:775) and asymmetric per-tensor (:738);
+    the byte is the low byte of the integer code in every case."""
+    res, dev = _run(w_fp16, _lib.INT_ASYM if asym else _lib.INT_SYM, wq_bits, group_size)
+    w_deq = res.deq.reshape(w_fp16.shape)
+    lead = w_fp16.shape[:-1]
+    if _is_per_tensor(group_size):
+        q = res.codes.reshape(w_fp16.shape)
+        q = q.view(torch.int8) if asym else q
+        scale = res.scale.reshape(())
+        zp = res.zero_point.reshape(()) if asym else None
+    else:
+        if _is_per_group(group_size):
+            K, C = w_fp16.shape
+            q = res.codes.reshape(K, C // group_size, group_size)
+            sshape = (K, C // group_size)
+        else:
+            q = res.codes.reshape(w_fp16.shape)
+            sshape = tuple(lead)
+        q = q if asym else q.view(torch.int8)
+        scale = res.scale.reshape(sshape)
+        zp = res.zero_point.reshape(sshape) if asym else None
+    return w_deq.to(dev), q.to(dev), scale.to(dev), (zp.to(dev) if zp is not None else None)
+
+
+@torch.no_grad()
+def _fp_quant_meta(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Optional[int] = None):
+    """(w_deq float16, q float16 table values, scale float16) -- quant_weight.py:778-872."""
+    _check_table(wq_bits, datatype)
+    res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype)
+    w_deq = res.deq.reshape(w_fp16.shape)
+    if _is_per_tensor(group_size):
+        q, scale = res.codes.reshape(w_fp16.shape), res.scale.reshape(())
+    elif _is_per_group(group_size):
+        K, C = w_fp16.shape
+        q, scale = res.codes.reshape(K, C // group_size, group_size), res.scale.reshape(K, C // group_size)
+    else:
+        q, scale = res.codes.reshape(w_fp16.shape), res.scale.reshape(tuple(w_fp16.shape[:-1]))
+    return w_deq.to(dev), q.to(dev), scale.to(dev)
+
+
+class _LinearDump(nn.Linear):
+    """nn.Linear carrying weight_q / weight_scale / weight_zp buffers (quant_weight.py:876-914).
+    As in the reference the buffers come from quantizing the weight it is given -- which quant_model has
+    already replaced by its dequantized value."""
+
+    def __init__(self, src: nn.Linear, wq_bits: int, mode: str, group_size: Optional[int]):
+        super().__init__(src.in_features, src.out_features, bias=src.bias is not None,
+                         device=src.weight.device, dtype=src.weight.dtype)
+        self.weight = nn.Parameter(src.weight.detach())
+        if src.bias is not None:
+            self.bias = nn.Parameter(src.bias.detach())
+        if mode.startswith("int"):
+            _, q, scale, zp = _int_quant_meta(self.weight.data, wq_bits=wq_bits, asym="asym" in mode,
+                                              group_size=group_size)
+        else:
+            _, q, scale = _fp_quant_meta(self.weight.data, wq_bits=wq_bits, datatype=mode, group_size=group_size)
+            zp = None
+        self.register_buffer("weight_q", q.to(torch.float16))
+        self.register_buffer("weight_scale", scale.to(torch.float16))
+        if zp is not None:
+            self.register_buffer("weight_zp", zp)
+
+    def forward(self, x):
+        out = F.linear(x, self.weight, self.bias)
+        keep = self.weight_q.float().sum() + self.weight_scale.float().sum()
+        if hasattr(self, "weight_zp"):
+            keep = keep + self.weight_zp.float().sum()
+        return out + keep * 0.0
+
+
+def _linears(model):
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, nn.Linear)]
+
+
+def quant_model(model, wq_bits: Optional[int] = None, wq_datatype: Optional[str] = None,
+                wq_groupsize: Optional[int] = None, _dump_int: bool = True):
+    """Fake-quantize every nn.Linear weight in place, then (unless _dump_int is False) swap each Linear
+    for a _LinearDump holding codes / scales / zero-points (quant_weight.py:652-706, :921-936).
+    Dispatch on the datatype string follows the reference's order."""
+    if wq_datatype is None or wq_datatype in ("fp16", "fp32"):
+        print("Not applying quantization")
+        return
+    if wq_datatype.startswith("int"):
+        fn = quant_int_asym if "asym" in wq_datatype else quant_int
+        kind = "asymmetric" if "asym" in wq_datatype else "symmetric"
+        print(f"Applying {kind} INT quantization with bits: {wq_bits}, group size: {wq_groupsize}")
+        for name, m in _linears(model):
+            m.weight.data = fn(m.weight.data, wq_bits=wq_bits, group_size=wq_groupsize)
+    elif "mx" in wq_datatype or "mixed" in wq_datatype:
+        raise NotImplementedError(f"{wq_datatype}: MX / mixed-datatype search have no MI355X kernel yet")
+    elif "fp" in wq_datatype:
+        print(f"Applying floating-point datatype quantization with bits: {wq_bits}, group size: {wq_groupsize}")
+        for name, m in _linears(model):
+            m.weight.data = quant_datatype(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype,
+                                           group_size=wq_groupsize)
+    else:
+        raise ValueError(f"Unsupported datatype {wq_datatype}")
+
+    if not _dump_int:
+        return
+    for name, mod in _linears(model):
+        parent, attr = _find_parent(model, name)
+        setattr(parent, attr, _LinearDump(mod, wq_bits, wq_datatype, wq_groupsize))
+
+
+def _find_parent(root: nn.Module, target_name: str):
+    parts = target_name.split(".")
+    for p in parts[:-1]:
+        root = getattr(root, p)
+    return root, parts[-1]

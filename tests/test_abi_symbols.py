@@ -1,0 +1,46 @@
+"""CPU: libmq.so loads and exports every function include/mq.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "mq.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_header_symbols():
+    from quantization_amd import _lib
+    names = declared_functions()
+    assert "mq_quantize" in names and "mq_version" in names
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"libmq.so does not export {n}"
+    assert _lib.lib().mq_version() >= 100
+    assert _lib.lib().mq_strerror(-2).decode().startswith("cols")
+
+
+def test_struct_layout_matches_header():
+    from quantization_amd import _lib
+    # mq_quant_cfg: 6 x int32 + int64; mq_quant_out: 5 pointers, 2 x int32, 2 pointers
+    assert ctypes.sizeof(_lib.QuantCfg) == 32
+    assert ctypes.sizeof(_lib.QuantOut) == 5 * 8 + 8 + 2 * 8
+
+
+def test_argument_validation_needs_no_gpu():
+    """Status codes that are decided before any HIP call."""
+    from quantization_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.QuantCfg(format=_lib.INT_SYM, bits=8, group_size=64)
+    out = _lib.QuantOut()
+    assert L.mq_quantize(None, _lib.F16, 4, 100, ctypes.byref(cfg), ctypes.byref(out), None, 0, None) == _lib.ERR_GROUP
+    cfg.group_size = 0
+    cfg.bits = 9
+    assert L.mq_quantize(None, _lib.F16, 4, 64, ctypes.byref(cfg), ctypes.byref(out), None, 0, None) == _lib.ERR_UNSUPPORTED
+    cfg.bits = 8
+    assert L.mq_quantize(None, 7, 4, 64, ctypes.byref(cfg), ctypes.byref(out), None, 0, None) == _lib.ERR_ARG
+    assert L.mq_quantize(None, _lib.F16, 0, 64, ctypes.byref(cfg), ctypes.byref(out), None, 0, None) == _lib.OK
+    assert L.mq_quantize(None, _lib.F16, 4, 64, ctypes.byref(cfg), ctypes.byref(out), None, 0, None) == _lib.ERR_ARG

@@ -1,0 +1,238 @@
+"""GPU: the HIP quantize path (through the C ABI, via the reference-shaped Python API) against the
+golden vectors and against the CPU oracle on seeded inputs.  Bit-exact for codes, scales, zero-points,
+dequantized values and element-wise errors; sums of squares within 1e-12 relative of a float64 sum of
+the same float32 squares."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import quantization_amd
+    from quantization_amd import _lib
+    _lib.lib()  # the native library must be there: no fallback
+    assert torch.cuda.is_available()
+    return quantization_amd
+
+
+def to_dev(arr, dt):
+    if dt == "f32":
+        return torch.from_numpy(arr.copy()).cuda()
+    t = torch.from_numpy(arr.view(np.int16).copy()).cuda()
+    return t.view(torch.float16 if dt == "f16" else torch.bfloat16)
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def fmt_args(orc, fmt):
+    if fmt == "int8":
+        return dict(fmt=orc.INT_SYM, bits=8)
+    if fmt == "int8_asym":
+        return dict(fmt=orc.INT_ASYM, bits=8)
+    return dict(fmt=orc.LUT, bits=8, datatype=fmt)
+
+
+def run_api(qa, w, fmt, gs):
+    """The reference-shaped API -> dict of bit arrays like gen_golden.run_reference."""
+    qw = qa.quant_weight
+    out = {}
+    if fmt.startswith("int"):
+        asym = "asym" in fmt
+        d, q, s, zp = qw._int_quant_meta(w, wq_bits=8, asym=asym, group_size=gs)
+        d2 = (qw.quant_int_asym if asym else qw.quant_int)(w, wq_bits=8, group_size=gs)
+        assert torch.equal(d.view(torch.int16), d2.view(torch.int16))
+        out["q_is_int8"] = q.dtype == torch.int8
+        out["q"] = q.contiguous().view(torch.uint8).cpu().numpy()
+        if zp is not None:
+            out["zp"] = bits16(zp.reshape(-1))
+    else:
+        d, q, s = qw._fp_quant_meta(w, wq_bits=8, datatype=fmt, group_size=gs)
+        out["q"] = bits16(q)
+        out["deq_quant_datatype"] = bits16(qw.quant_datatype(w, wq_bits=8, datatype=fmt, group_size=gs))
+    assert d.dtype == torch.float16 and s.dtype == torch.float16 and d.shape == w.shape
+    out["deq"] = bits16(d)
+    out["scale"] = bits16(s.reshape(-1))
+    out["shapes"] = (tuple(q.shape), tuple(s.shape))
+    return out
+
+
+def assert_same(got, exp, what):
+    for k in ("deq", "q", "scale", "zp", "deq_quant_datatype"):
+        if k in exp:
+            assert k in got, f"{what}: missing {k}"
+            assert got[k].shape == exp[k].shape, f"{what}: {k} shape {got[k].shape} != {exp[k].shape}"
+            bad = np.flatnonzero(got[k].reshape(-1) != exp[k].reshape(-1))
+            assert bad.size == 0, f"{what}: {k} differs at {bad.size} positions, first {bad[:5]}"
+    if "q_is_int8" in exp:
+        assert bool(exp["q_is_int8"]) == got["q_is_int8"], f"{what}: code dtype"
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", gu.GROUPS, ids=gu.gs_key)
+def test_golden_small(qa, fmt, gs):
+    for key, dt, arr in gu.small_inputs():
+        got = run_api(qa, to_dev(arr, dt), fmt, gs)
+        assert_same(got, gu.small_expected(key, fmt, gs), f"{key}/{fmt}/{gs}")
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", [None, 128], ids=gu.gs_key)
+def test_golden_exhaustive(qa, fmt, gs):
+    arr, exp = gu.exhaustive_expected(fmt, gs)
+    assert_same(run_api(qa, to_dev(arr, "f16"), fmt, gs), exp, f"exhaustive/{fmt}/{gs}")
+
+
+@pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp8_e3m4"])
+def test_golden_lut_domain(qa, fmt):
+    z = gu.npz("lut_domain.npz")
+    w = to_dev(z[f"{fmt}/in"], "f16")
+    d, q, s = qa.quant_weight._fp_quant_meta(w, wq_bits=8, datatype=fmt, group_size=None)
+    assert torch.all(s == 1.0)
+    assert np.array_equal(bits16(q), z[f"{fmt}/q"])
+    assert np.array_equal(bits16(d), z[f"{fmt}/deq"])
+
+
+# (rows, cols, group sizes): every kernel scope -- part-of-wave teams, wave per row, workgroup per row
+# (256 and 1024 threads), the scalar fallback (odd lengths), and ragged tails
+SHAPES = [
+    (33, 256, [None, 8, 16, 32, 64, 128, 256, -1]),
+    (7, 1024, [None, 512, 1024]),
+    (5, 1536, [None, 96, 48, 768]),       # group sizes that are not powers of two
+    (3, 4096, [None, 128]),
+    (3, 8192, [None, 2048]),
+    (2, 14336, [None, 128]),
+    (2, 28672, [None, 64]),
+    (1, 65536, [None, -1]),
+    (2, 136000, [None]),                  # longer than a 1024-thread team holds -> fallback
+    (6, 100, [None, 20, 10, -1]),         # no 8-element vectors -> fallback
+    (1, 8, [None, -1]),
+    (300, 40, [None, 8]),
+]
+
+
+def _rand(rows, cols, dt, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(rows, cols, generator=g) * 0.02
+    w[0, 0] = 0.7  # an outlier
+    if rows > 2:
+        w[2] = 0  # a zero row
+    return {"f16": w.half(), "bf16": w.bfloat16(), "f32": w.float()}[dt]
+
+
+def _np_in(wt, dt, orc):
+    if dt == "f32":
+        return wt.numpy(), orc.F32
+    a = wt.view(torch.int16).numpy().view(np.uint16)
+    return (a, orc.F16) if dt == "f16" else (a, orc.BF16)
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_vs_oracle_shapes(qa, oracle, fmt, dt):
+    from quantization_amd import _lib
+    fmt_code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
+    for si, (rows, cols, groups) in enumerate(SHAPES):
+        if dt != "f16" and cols > 30000:
+            continue
+        wt = _rand(rows, cols, dt, 100 + si)
+        arr, code = _np_in(wt, dt, oracle)
+        wd = wt.cuda()
+        for gs in groups:
+            exp = oracle.quantize(arr, code, group_size=gs, **fmt_args(oracle, fmt))
+            res = qa.quantize(wd, fmt_code, 8, gs, fmt if fmt_code == _lib.LUT_FP else None,
+                              abs_err=torch.float32, seg_sse=True, totals=True)
+            what = f"{rows}x{cols} gs={gs} {fmt} {dt}"
+            got = {"deq": bits16(res.deq), "scale": bits16(res.scale)}
+            got["q"] = bits16(res.codes) if fmt_code == _lib.LUT_FP else res.codes.cpu().numpy()
+            if res.zero_point is not None:
+                got["zp"] = bits16(res.zero_point)
+            assert_same(got, exp, what)
+            # element-wise float32 error and its sums (onnx_error_cli.py:90-91, quant_error_multi_weight.py:55-58)
+            v32 = exp["v16"].view(np.float16).astype(np.float32)
+            d32 = exp["deq"].view(np.float16).astype(np.float32)
+            err = v32 - d32
+            assert np.array_equal(res.abs_err.cpu().numpy().view(np.uint32), np.abs(err).view(np.uint32)), what
+            sq = (err * err).astype(np.float64)
+            L = rows * cols if gs == -1 else (cols if (gs is None or gs <= 0) else gs)
+            seg = sq.reshape(-1, L).sum(axis=1)
+            np.testing.assert_allclose(res.seg_sse.cpu().numpy(), seg, rtol=1e-12, atol=0, err_msg=what)
+            tot = res.totals.cpu().numpy()
+            np.testing.assert_allclose(tot[0], sq.sum(), rtol=1e-12, err_msg=what)
+            np.testing.assert_allclose(tot[1], np.abs(err).astype(np.float64).sum(), rtol=1e-12, err_msg=what)
+            # float16 error variant (single_weight_quant_error.py:39-40)
+            res16 = qa.quantize(wd, fmt_code, 8, gs, fmt if fmt_code == _lib.LUT_FP else None,
+                                deq=False, codes=False, scale=False, abs_err=torch.float16)
+            e16 = np.abs(exp["v16"].view(np.float16) - exp["deq"].view(np.float16))
+            assert np.array_equal(bits16(res16.abs_err), e16.view(np.uint16)), what
+
+
+def test_return_shapes_and_dtypes(qa):
+    qw = qa.quant_weight
+    w = (torch.randn(16, 256) * 0.02).half().cuda()
+    d, q, s, zp = qw._int_quant_meta(w, 8, False, 64)
+    assert q.shape == (16, 4, 64) and q.dtype == torch.int8 and s.shape == (16, 4) and zp is None
+    d, q, s, zp = qw._int_quant_meta(w, 8, True, 64)
+    assert q.shape == (16, 4, 64) and q.dtype == torch.uint8 and zp.shape == (16, 4) and zp.dtype == torch.float16
+    d, q, s, zp = qw._int_quant_meta(w, 8, True, None)
+    assert q.shape == (16, 256) and s.shape == (16,) and zp.shape == (16,)
+    d, q, s, zp = qw._int_quant_meta(w, 8, False, -1)
+    assert q.dtype == torch.uint8 and s.shape == () and zp is None
+    d, q, s, zp = qw._int_quant_meta(w, 8, True, -1)
+    assert q.dtype == torch.int8 and s.shape == () and zp.shape == ()
+    d, q, s = qw._fp_quant_meta(w, 8, "fp8_e4m3", 32)
+    assert d.shape == (16, 256) and q.shape == (16, 8, 32) and q.dtype == torch.float16 and s.shape == (16, 8)
+    # a 3-D tensor with group_size=None reduces over the last axis (search_datatype's call shape, :640)
+    w3 = w.reshape(16, 4, 64)
+    d3 = qw.quant_datatype(w3, 8, "fp8_e3m4", None)
+    d2 = qw.quant_datatype(w, 8, "fp8_e3m4", 64)
+    assert d3.shape == (16, 4, 64) and torch.equal(d3.reshape(16, 256).view(torch.int16), d2.view(torch.int16))
+    # host tensors go through the device and come back on the host
+    dc = qw.quant_int(w.cpu(), 8, 64)
+    assert dc.device.type == "cpu" and torch.equal(dc.view(torch.int16), qw.quant_int(w, 8, 64).cpu().view(torch.int16))
+
+
+def test_errors_match_reference_types(qa):
+    qw = qa.quant_weight
+    w = (torch.randn(4, 100) * 0.02).half().cuda()
+    with pytest.raises(RuntimeError):
+        qw.quant_int(w, 8, 64)            # 100 % 64 != 0: torch reshape error in the reference
+    with pytest.raises(ValueError):
+        qw.quant_datatype(w, 7, "fp8_e4m3", None)   # unsupported bit width
+    with pytest.raises(AssertionError):
+        qw.quant_datatype(w, 8, "fp8_bogus", None)  # unknown table name
+    with pytest.raises(ValueError):
+        qw.quant_int(w.reshape(2, 2, 50), 8, 10)    # per-group needs a 2-D weight
+    assert qw.quant_int(torch.empty(0, 64, dtype=torch.float16, device="cuda"), 8, None).shape == (0, 64)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 4, 5, 6, 7])
+def test_low_bit_int(qa, oracle, bits):
+    wt = _rand(16, 512, "f16", 7)
+    arr, code = _np_in(wt, "f16", oracle)
+    for asym in (False, True):
+        for gs in (None, 128):
+            exp = oracle.quantize(arr, code, oracle.INT_ASYM if asym else oracle.INT_SYM, bits, gs)
+            d, q, s, zp = qa.quant_weight._int_quant_meta(wt.cuda(), bits, asym, gs)
+            assert np.array_equal(bits16(d), exp["deq"]) and np.array_equal(bits16(s.reshape(-1)), exp["scale"])
+            assert np.array_equal(q.contiguous().view(torch.uint8).cpu().numpy().reshape(16, 512), exp["q"])
+
+
+def test_quant_model_walker(qa):
+    import torch.nn as nn
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Linear(256, 128), nn.ReLU(), nn.Linear(128, 64, bias=False)).half().cuda()
+    w0 = model[0].weight.data.clone()
+    qa.quant_weight.quant_model(model, 8, "int8_asym", 64)
+    assert type(model[0]).__name__ == "_LinearDump" and model[0].weight_q.dtype == torch.float16
+    assert model[0].weight_zp.shape == (128, 4) and model[2].weight_scale.shape == (64, 2)
+    assert torch.equal(model[0].weight.data.view(torch.int16),
+                       qa.quant_weight.quant_int_asym(w0, 8, 64).view(torch.int16))
+    y = model(torch.randn(2, 256, device="cuda", dtype=torch.float16))
+    assert y.shape == (2, 64)
