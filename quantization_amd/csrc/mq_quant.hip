@@ -108,16 +108,25 @@ __device__ __forceinline__ uint32_t absmax8(u32x4 v) {
   for (int k = 1; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, v[k] & 0x7fff7fffu));
   return m[0] > m[1] ? m[0] : m[1];
 }
+// Packed float16 min / max.  Written as instructions: hipcc (ROCm 7.2) drops all but the first
+// __builtin_elementwise_min/max of a chain over _Float16 vectors.
+__device__ __forceinline__ uint32_t pk_min_f16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ void minmax8(u32x4 v, half_t& mn, half_t& mx) {
-  h16x2 lo = __builtin_bit_cast(h16x2, v[0]), hi = lo;
-#pragma unroll
-  for (int k = 1; k < 4; ++k) {
-    h16x2 x = __builtin_bit_cast(h16x2, v[k]);
-    lo = __builtin_elementwise_min(lo, x);
-    hi = __builtin_elementwise_max(hi, x);
-  }
-  mn = lo[0] < lo[1] ? lo[0] : lo[1];
-  mx = hi[0] > hi[1] ? hi[0] : hi[1];
+  uint32_t lo = pk_min_f16(pk_min_f16(v[0], v[1]), pk_min_f16(v[2], v[3]));
+  uint32_t hi = pk_max_f16(pk_max_f16(v[0], v[1]), pk_max_f16(v[2], v[3]));
+  half_t l0 = h_from_bits(lo & 0xffffu), l1 = h_from_bits(lo >> 16);
+  half_t h0 = h_from_bits(hi & 0xffffu), h1 = h_from_bits(hi >> 16);
+  mn = l0 < l1 ? l0 : l1;
+  mx = h0 > h1 ? h0 : h1;
 }
 
 template <int T>
@@ -180,11 +189,13 @@ __device__ __forceinline__ SegP params_minmax(half_t rmin, half_t rmax, float qm
 
 // h(v / s).  q1 below equals the IEEE float32 quotient v/s for every finite float16 v and every float16
 // s in [0x00A8, 0x70E2] (the clamped scale range) -- checked exhaustively on the CPU, see
-// tests/test_division_shortcut.py -- so rounding it to float16 is h(v / s).  An infinite v keeps q0.
+// tests/test_division_shortcut.py -- so rounding it to float16 is h(v / s).
 __device__ __forceinline__ half_t div_h(float vf, const SegP& sp) {
   float q0 = vf * sp.r;
   float q1 = __builtin_fmaf(__builtin_fmaf(-q0, sp.sf, vf), sp.r, q0);
-  q1 = __builtin_isinf(q0) ? q0 : q1;
+  // +-0 and +-inf quotients are already exact in q0; the correction step would turn -0 into +0 and
+  // inf into NaN (class mask: -inf | -0 | +0 | +inf)
+  q1 = __builtin_amdgcn_classf(q0, 0x264) ? q0 : q1;
   return (half_t)q1;
 }
 

@@ -208,7 +208,7 @@ def test_errors_match_reference_types(qa):
     with pytest.raises(AssertionError):
         qw.quant_datatype(w, 8, "fp8_bogus", None)  # unknown table name
     with pytest.raises(ValueError):
-        qw.quant_int(w.reshape(2, 2, 50), 8, 10)    # per-group needs a 2-D weight
+        qw.quant_int(w.reshape(4, 2, 50), 8, 10)    # per-group needs a 2-D weight
     assert qw.quant_int(torch.empty(0, 64, dtype=torch.float16, device="cuda"), 8, None).shape == (0, 64)
 
 
