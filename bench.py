@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the quantize -> dequantize -> error hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|llama8b|tinyllama]
+
+For N > 1 the driver starts one rank per GPU with torch.distributed.run; every rank processes its own
+copy of the workload (weak scaling: the units are independent weight tensors, no data-path collective)
+and the per-tensor statistics records are all-gathered once per step over RCCL.
+
+Default workload "c2" (BASELINE.json configs[1]): 4096x4096 fp16 matrices, asymmetric int8 with
+group sizes 32 / 64 / 128, returning dequantized weights, codes, scales, zero-points and the float32
+element-wise absolute-error dump, plus per-group and per-tensor squared-error sums.  A step is one
+pass over a batch of 16 distinct matrices (512 MiB of weights, 5.4 GB of outputs -- more than the
+256 MiB Infinity Cache, so inputs come from HBM) x 3 group sizes = 48 fused launches.
+
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import quantization_amd as qa  # noqa: E402
+from quantization_amd import _lib  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+TINYLLAMA = [(2048, 2048)] * 2 + [(256, 2048)] * 2 + [(5632, 2048)] * 2 + [(2048, 5632)]
+LLAMA8B = [(4096, 4096)] * 2 + [(1024, 4096)] * 2 + [(14336, 4096)] * 2 + [(4096, 14336)]
+
+
+def model_shapes(per_layer, layers, head):
+    return per_layer * layers + [head]
+
+
+def algorithmic_bytes_per_elem(in_bytes, fmt, gs, outputs):
+    """HBM bytes one fused launch must move per weight element: input once, plus each requested output."""
+    b = float(in_bytes)
+    if outputs.get("deq"):
+        b += 2
+    if outputs.get("codes"):
+        b += 2 if fmt == _lib.LUT_FP else 1
+    if outputs.get("abs_err") == torch.float32:
+        b += 4
+    elif outputs.get("abs_err") == torch.float16:
+        b += 2
+    if gs and gs > 0:
+        per_seg = (2 if outputs.get("scale") else 0) * (2 if fmt == _lib.INT_ASYM else 1)
+        per_seg += 8 if outputs.get("seg_sse") else 0
+        b += per_seg / gs
+    return b
+
+
+class Workload:
+    def __init__(self, name, device, rank):
+        self.name = name
+        g = torch.Generator(device=device)
+        self.passes = []  # (weight tensor, fmt, datatype, gs, outputs dict)
+        self.results = {}
+        if name == "c2":
+            self.desc = ("16x 4096x4096 fp16 N(0,0.02^2), int8-asym g=32/64/128: deq + codes + scale + zp + "
+                         "abs-err(f32) dump + per-group/tensor SSE")
+            outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True, totals=True)
+            self.weights = []
+            for i in range(16):
+                g.manual_seed(1000 * rank + i)
+                self.weights.append((torch.randn(4096, 4096, generator=g, device=device) * 0.02).half())
+            for gs in (32, 64, 128):
+                for i, w in enumerate(self.weights):
+                    self.passes.append((i, w, _lib.INT_ASYM, None, gs, outs))
+        else:
+            shapes = (model_shapes(TINYLLAMA, 22, (32000, 2048)) if name == "tinyllama"
+                      else model_shapes(LLAMA8B, 32, (128256, 4096)))
+            dt = torch.float16 if name == "tinyllama" else torch.bfloat16
+            self.desc = (f"{name}-shaped random-init {str(dt).split('.')[-1]} linear weights ({len(shapes)} tensors), "
+                         "int8-sym per-channel, stats only (per-row/tensor SSE, sum|err|)")
+            outs = dict(deq=False, codes=False, scale=True, abs_err=None, seg_sse=True, totals=True)
+            self.weights = []
+            for i, (r, c) in enumerate(shapes):
+                g.manual_seed(1000 * rank + i)
+                self.weights.append((torch.randn(r, c, generator=g, device=device) * 0.02).to(dt))
+            for i, w in enumerate(self.weights):
+                self.passes.append((i, w, _lib.INT_SYM, None, None, outs))
+        self.weight_bytes = sum(w.numel() * w.element_size() for _, w, *_ in self.passes)
+        self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f, gs, o)
+                              for _, w, f, _, gs, o in self.passes)
+        self.launches = len(self.passes)
+        self.stats = torch.zeros(len(self.passes), 2, dtype=torch.float64, device=device)
+
+    def step(self):
+        for k, (i, w, fmt, dt, gs, outs) in enumerate(self.passes):
+            # one preallocated output set per pass: outputs cycle through > 256 MiB so they reach HBM
+            res = self.results.get((i, gs))
+            res = qa.quantize(w, fmt, 8, gs, dt, out=res, **outs)
+            self.results[(i, gs)] = res
+            self.stats[k].copy_(res.totals, non_blocking=True)
+        return self.stats
+
+
+def cpu_baseline(nthreads):
+    """The CPU port (oracle/: C restatement of quant_weight.py + the analysis scripts' numpy) on a bounded
+    sample of the c2 workload: ONE 4096x4096 fp16 matrix x g = 32 / 64 / 128, asymmetric int8 with
+    deq/codes/scale/zp, float32 error, tensor MSE, abs-error sum and P99, per-group MSE vector + P99."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((4096, 4096)) * 0.02).astype(np.float16)
+    orc.quantize(w[:64], orc.F16, orc.INT_ASYM, 8, 128, nthreads=nthreads)  # load the library
+    t0 = time.perf_counter()
+    for gs in (32, 64, 128):
+        o = orc.quantize(w, orc.F16, orc.INT_ASYM, 8, gs, nthreads=nthreads)
+        deq = o["deq"].view(np.float16)
+        a32, b32 = orc.proto_to_array(w), orc.proto_to_array(deq)
+        orc.compute_mse(a32, b32)
+        orc.elementwise_f32(w, deq)
+        # per-(row, group) MSE vector + mean + P99 (quant_error_single_weight.py:61-79), vectorised
+        d = (a32 - b32).reshape(-1, gs)
+        vec = np.mean(d * d, axis=1, dtype=np.float32).astype(np.float64)
+        vec.mean(), np.percentile(vec, 99)
+    dt = time.perf_counter() - t0
+    return {"value": round(3 * w.nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": nthreads, "kind": "port",
+            "sample": "1 of the 16 matrices x g=32/64/128 (3 passes, 96 MiB of weights): C oracle quantize "
+                      f"({nthreads} OpenMP threads) + numpy MSE / abs-err sum / P99 / per-group MSE vector; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "tinyllama", "llama8b"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    _lib.lib()
+
+    wl = Workload(args.workload, device, rank)
+    gathered = torch.zeros(world, *wl.stats.shape, dtype=torch.float64, device=device) if world > 1 else None
+
+    def one_step():
+        stats = wl.step()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, stats)  # per-tensor statistics records -> every rank
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        one_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+
+    # dominant kernel: back-to-back fused launches only (no stats copies), HIP events on the launch stream
+    reps = 3
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        for k, (i, w, fmt, dt, gs, outs) in enumerate(wl.passes):
+            qa.quantize(w, fmt, 8, gs, dt, out=wl.results[(i, gs)], **dict(outs, totals=False))
+    e1.record()
+    torch.cuda.synchronize()
+    kern_ms = e0.elapsed_time(e1) / (reps * wl.launches)
+    algo_per_launch = wl.algo_bytes / wl.launches
+    achieved = algo_per_launch / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.workload)
+        out = {
+            "metric": "weight GB/s quant+dequant+MSE/P99",
+            "value": round(world * wl.weight_bytes * args.steps / wall / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl.desc}", "launches_per_step": wl.launches,
+                       "weight_bytes_per_step_per_gpu": wl.weight_bytes,
+                       "algorithmic_bytes_per_step_per_gpu": int(wl.algo_bytes),
+                       "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "fused quantize (mq_quantize)", "avg_launch_us": round(kern_ms * 1e3, 2),
+                         "algorithmic_bytes_per_launch": int(algo_per_launch)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 16))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,10 @@ def lib():
         L.orc_f2h.restype = ctypes.c_uint16
         L.orc_h2f.argtypes = [ctypes.c_uint16]
         L.orc_h2f.restype = ctypes.c_float
+        L.orc_f2h_soft.argtypes = [ctypes.c_float]
+        L.orc_f2h_soft.restype = ctypes.c_uint16
+        L.orc_h2f_soft.argtypes = [ctypes.c_uint16]
+        L.orc_h2f_soft.restype = ctypes.c_float
         L.orc_build_lut.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
         L.orc_build_lut.restype = ctypes.c_int
         _LIB = L

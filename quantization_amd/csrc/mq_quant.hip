@@ -1,11 +1,13 @@
 // Fused quantize -> dequantize -> error kernels for gfx950 (MI355X).
 //
 // One pass per weight tensor: each lane loads 8 consecutive elements (16 B of float16), the lanes that
-// share a scale ("team": part of a wave, a wave, or a workgroup) reduce absmax or min/max with
-// cross-lane shuffles (workgroup teams add one LDS exchange), every lane derives the segment's
-// scale / zero-point, quantizes and dequantizes its 8 elements from registers, stores the requested
-// outputs with 8/16-byte vector stores and accumulates the float32 error in float64.  The input is
-// read from HBM exactly once; the kernel is HBM-bandwidth bound (no contraction, no MFMA).
+// share a scale ("team": part of a wave, a wave, or a workgroup) reduce absmax or min/max across lanes
+// (DPP inside a 16-lane row, one LDS exchange for workgroup teams), every lane derives the segment's
+// scale / zero-point, quantizes and dequantizes its 8 elements from registers with packed float16
+// arithmetic, stores the requested outputs with 8/16-byte vector stores and accumulates the float32
+// error.  The input is read from HBM exactly once; there is no contraction, so no MFMA: the kernel is
+// bounded by HBM bandwidth once its VALU work per element is small enough, which is what the packed
+// formulation below is for.
 //
 // Arithmetic contract (reference: /root/reference/quant_utils/quant_weight.py :229-335, :503-601,
 // :717-872): the reference runs every op as its own float16 torch kernel, i.e. widen to float32,
@@ -15,7 +17,12 @@
 //   asym: s = clamp(h(h(rmax - rmin) / qmax));  zp = clamp(rint(h(-rmin / s)), 0, qmax)
 //         q = clamp(h(rint(h(v / s)) + zp), 0, qmax);                               d = h(h(q - zp) * s)
 //   lut : s = clamp(h(max|v| / LUTmax));  q = nearest table value to h(v / s), ties toward -inf;  d = h(q * s)
+// Every shortcut taken on the fast path is exact on its stated domain (proofs: exhaustive CPU sweeps in
+// tests/test_division_shortcut.py); segments outside that domain (inf / NaN, or |v/s| >= 500) take the
+// per-element slow path, which follows the contract literally.
 // This file must be compiled with -ffp-contract=off and without fast-math.
+#include <stdlib.h>
+
 #include "mq_common.h"
 
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
@@ -31,9 +38,11 @@ struct QuantParams {
   int64_t n;     // elements
   int64_t L;     // segment length in elements
   int64_t nseg;  // segments
-  int32_t team_log2;     // SC_SUBWAVE: log2(lanes per segment)
   int32_t vecs_per_seg;  // L / 8
+  int32_t need_err;      // any of abs_err / seg_sse / totals requested
   float qmax;            // sym: 2^(b-1)-1, asym: 2^b-1, lut: largest table value
+  float rqmax;           // RN(1 / qmax)
+  int32_t qmax_recip_ok; // a * rqmax with one correction step equals a / qmax for every float16 a
   LutConst lut;
   uint16_t* deq;
   void* codes;
@@ -47,11 +56,74 @@ struct QuantParams {
 };
 
 struct SegP {
-  half_t s;   // scale
-  float sf;   // (float)s
-  float r;    // RN(1 / sf)
-  half_t zp;  // zero-point (asym)
+  half_t s;    // scale
+  half_t zp;   // zero-point (asym)
+  float sf;    // (float)s
+  float r;     // ~1 / sf (v_rcp_f32, at most 1 ulp off: enough for div_h, see there)
+  bool slow;   // this segment must take the per-element path
 };
+
+// ------------------------------------------------------------------------------------------------
+// small instruction wrappers
+// ------------------------------------------------------------------------------------------------
+// Packed 16-bit min / max / saturating subtract.  Written as instructions: hipcc (ROCm 7.2) drops all
+// but the first __builtin_elementwise_min/max of a chain over _Float16 vectors.
+#define MQ_PK_OP(name, insn)                                            \
+  __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b) {    \
+    uint32_t r;                                                         \
+    asm(insn " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                 \
+    return r;                                                           \
+  }
+MQ_PK_OP(pk_min_f16, "v_pk_min_f16")
+MQ_PK_OP(pk_max_f16, "v_pk_max_f16")
+MQ_PK_OP(pk_min_u16, "v_pk_min_u16")
+MQ_PK_OP(pk_max_u16, "v_pk_max_u16")
+MQ_PK_OP(pk_add_u16, "v_pk_add_u16")
+MQ_PK_OP(pk_sub_u16, "v_pk_sub_u16")
+__device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ h16x2 as_h2(uint32_t w) { return __builtin_bit_cast(h16x2, w); }
+__device__ __forceinline__ uint32_t as_u32(h16x2 h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ uint32_t dup16(uint32_t b) { return (b & 0xffffu) | (b << 16); }
+
+// Cross-lane moves inside a 16-lane row (DPP): partner lane^1, lane^2, and the mirrored partner in the
+// row's 8-lane halves / in the row, which serve as the lane^4 / lane^8 steps of a butterfly.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140 };
+
+template <int T, typename F>
+__device__ __forceinline__ uint32_t team_reduce_u32(uint32_t m, F op) {
+  if constexpr (T >= 2) m = op(m, dpp<DPP_XOR1>(m));
+  if constexpr (T >= 4) m = op(m, dpp<DPP_XOR2>(m));
+  if constexpr (T >= 8) m = op(m, dpp<DPP_HALF_MIRROR>(m));
+  if constexpr (T >= 16) m = op(m, dpp<DPP_MIRROR>(m));
+  if constexpr (T >= 32) m = op(m, (uint32_t)__shfl_xor((int)m, 16));
+  if constexpr (T >= 64) m = op(m, (uint32_t)__shfl_xor((int)m, 32));
+  return m;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  uint64_t u = __builtin_bit_cast(uint64_t, v);
+  uint32_t lo = dpp<CTRL>((uint32_t)u), hi = dpp<CTRL>((uint32_t)(u >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+// fixed butterfly order -> bitwise reproducible
+template <int T>
+__device__ __forceinline__ double team_sum(double v) {
+  if constexpr (T >= 2) v += dpp_f64<DPP_XOR1>(v);
+  if constexpr (T >= 4) v += dpp_f64<DPP_XOR2>(v);
+  if constexpr (T >= 8) v += dpp_f64<DPP_HALF_MIRROR>(v);
+  if constexpr (T >= 16) v += dpp_f64<DPP_MIRROR>(v);
+  if constexpr (T >= 32) v += __shfl_xor(v, 16);
+  if constexpr (T >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // loads: 8 consecutive elements of the caller's tensor as packed float16 (w.to(torch.float16))
@@ -62,16 +134,19 @@ __device__ __forceinline__ u32x4 load8_f16(const void* w, int dtype, int64_t e) 
   if (dtype == MQ_BF16) {
     u32x4 b = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      out[k] = f2h_bits(f_from_bits(b[k] << 16)) | (f2h_bits(f_from_bits(b[k] & 0xffff0000u)) << 16);
+    for (int k = 0; k < 4; ++k) {
+      h16x2 h;
+      h[0] = (half_t)f_from_bits(b[k] << 16);
+      h[1] = (half_t)f_from_bits(b[k] & 0xffff0000u);
+      out[k] = as_u32(h);
+    }
     return out;
   }
   const f32x4* p = reinterpret_cast<const f32x4*>(static_cast<const float*>(w) + e);
   f32x4 a = p[0], c = p[1];
-  out[0] = f2h_bits(a[0]) | (f2h_bits(a[1]) << 16);
-  out[1] = f2h_bits(a[2]) | (f2h_bits(a[3]) << 16);
-  out[2] = f2h_bits(c[0]) | (f2h_bits(c[1]) << 16);
-  out[3] = f2h_bits(c[2]) | (f2h_bits(c[3]) << 16);
+  h16x2 h0 = {(half_t)a[0], (half_t)a[1]}, h1 = {(half_t)a[2], (half_t)a[3]};
+  h16x2 h2 = {(half_t)c[0], (half_t)c[1]}, h3 = {(half_t)c[2], (half_t)c[3]};
+  out[0] = as_u32(h0); out[1] = as_u32(h1); out[2] = as_u32(h2); out[3] = as_u32(h3);
   return out;
 }
 
@@ -101,60 +176,32 @@ __device__ __forceinline__ void load8_f32(const void* w, int dtype, int64_t e, f
 // per-lane reductions over one 8-element vector
 // ------------------------------------------------------------------------------------------------
 // max |v| as an integer max over the sign-cleared float16 bits: order-preserving, and a NaN (> 0x7c00)
-// wins, which is torch.amax's NaN propagation.
-__device__ __forceinline__ uint32_t absmax8(u32x4 v) {
-  u16x2 m = __builtin_bit_cast(u16x2, v[0] & 0x7fff7fffu);
-#pragma unroll
-  for (int k = 1; k < 4; ++k) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2, v[k] & 0x7fff7fffu));
-  return m[0] > m[1] ? m[0] : m[1];
+// wins, which is torch.amax's NaN propagation.  Returns the packed maximum of the even / odd elements.
+__device__ __forceinline__ uint32_t absmax8_pk(u32x4 v) {
+  const uint32_t m = 0x7fff7fffu;
+  return pk_max_u16(pk_max_u16(v[0] & m, v[1] & m), pk_max_u16(v[2] & m, v[3] & m));
 }
-// Packed float16 min / max.  Written as instructions: hipcc (ROCm 7.2) drops all but the first
-// __builtin_elementwise_min/max of a chain over _Float16 vectors.
-__device__ __forceinline__ uint32_t pk_min_f16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+__device__ __forceinline__ uint32_t fold_max_u16(uint32_t pk) {
+  uint32_t a = pk & 0xffffu, b = pk >> 16;
+  return a > b ? a : b;
 }
-__device__ __forceinline__ uint32_t pk_max_f16(uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
+// packed (min over even, min over odd) / (max ...) of the signed float16 values
+__device__ __forceinline__ void minmax8_pk(u32x4 v, uint32_t& lo, uint32_t& hi) {
+  lo = pk_min_f16(pk_min_f16(v[0], v[1]), pk_min_f16(v[2], v[3]));
+  hi = pk_max_f16(pk_max_f16(v[0], v[1]), pk_max_f16(v[2], v[3]));
 }
-__device__ __forceinline__ void minmax8(u32x4 v, half_t& mn, half_t& mx) {
-  uint32_t lo = pk_min_f16(pk_min_f16(v[0], v[1]), pk_min_f16(v[2], v[3]));
-  uint32_t hi = pk_max_f16(pk_max_f16(v[0], v[1]), pk_max_f16(v[2], v[3]));
-  half_t l0 = h_from_bits(lo & 0xffffu), l1 = h_from_bits(lo >> 16);
-  half_t h0 = h_from_bits(hi & 0xffffu), h1 = h_from_bits(hi >> 16);
-  mn = l0 < l1 ? l0 : l1;
-  mx = h0 > h1 ? h0 : h1;
+// -> one word: min in the low half, max in the high half
+__device__ __forceinline__ uint32_t fold_minmax(uint32_t lo, uint32_t hi) {
+  // (lo.l, hi.l) vs (lo.h, hi.h): min of the low halves, max of the high halves
+  uint32_t a = (lo & 0xffffu) | (hi << 16), b = (lo >> 16) | (hi & 0xffff0000u);
+  uint32_t mn = pk_min_f16(a, b), mx = pk_max_f16(a, b);
+  return (mn & 0xffffu) | (mx & 0xffff0000u);
 }
-
-template <int T>
-__device__ __forceinline__ uint32_t team_max_u32(uint32_t m) {
-#pragma unroll
-  for (int off = 1; off < T; off <<= 1) {
-    uint32_t o = __shfl_xor(m, off);
-    m = o > m ? o : m;
-  }
-  return m;
+__device__ __forceinline__ uint32_t op_minmax(uint32_t a, uint32_t b) {
+  uint32_t mn = pk_min_f16(a, b), mx = pk_max_f16(a, b);
+  return (mn & 0xffffu) | (mx & 0xffff0000u);
 }
-// (min, max) packed as float16 bits in one word so that each step costs one shuffle
-template <int T>
-__device__ __forceinline__ void team_minmax(half_t& mn, half_t& mx) {
-#pragma unroll
-  for (int off = 1; off < T; off <<= 1) {
-    uint32_t o = __shfl_xor(h_bits(mn) | (h_bits(mx) << 16), off);
-    half_t omn = h_from_bits(o & 0xffffu), omx = h_from_bits(o >> 16);
-    mn = omn < mn ? omn : mn;
-    mx = omx > mx ? omx : mx;
-  }
-}
-template <int T>
-__device__ __forceinline__ double team_sum(double v) {
-#pragma unroll
-  for (int off = 1; off < T; off <<= 1) v += __shfl_xor(v, off);
-  return v;
-}
+__device__ __forceinline__ uint32_t op_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // ------------------------------------------------------------------------------------------------
 // segment parameters
@@ -166,42 +213,77 @@ __device__ __forceinline__ half_t clamp_scale(half_t s) {
   s = s > hi ? hi : s;
   return s;  // NaN stays NaN
 }
-__device__ __forceinline__ SegP finish_params(half_t s) {
-  SegP sp;
+// h(a / qmax) for a float16 a.  With RN(1/qmax) and one correction step the float32 quotient is exact
+// for every finite a when the host has verified it for this qmax (qmax_recip_ok); otherwise divide.
+__device__ __forceinline__ half_t div_qmax(half_t a, const QuantParams& p) {
+  float af = (float)a;
+  if (p.qmax_recip_ok) {
+    float q0 = af * p.rqmax;
+    return (half_t)__builtin_fmaf(__builtin_fmaf(-q0, p.qmax, af), p.rqmax, q0);
+  }
+  return (half_t)(af / p.qmax);
+}
+__device__ __forceinline__ void finish_params(SegP& sp, half_t s) {
   sp.s = s;
   sp.sf = (float)s;
-  sp.r = 1.0f / sp.sf;  // correctly rounded (IEEE) reciprocal: required by div_h()
-  sp.zp = (half_t)0;
-  return sp;
-}
-__device__ __forceinline__ SegP params_absmax(uint32_t amax_bits, float qmax) {
-  return finish_params(clamp_scale((half_t)((float)h_from_bits(amax_bits) / qmax)));
-}
-__device__ __forceinline__ SegP params_minmax(half_t rmin, half_t rmax, float qmax) {
-  half_t range = rmax - rmin;
-  SegP sp = finish_params(clamp_scale((half_t)((float)range / qmax)));
-  half_t z = __builtin_rintf16((half_t)((float)(-rmin) / sp.sf));
-  z = z < (half_t)0 ? (half_t)0 : z;
-  z = z > (half_t)qmax ? (half_t)qmax : z;
-  sp.zp = z;
-  return sp;
+  sp.r = __builtin_amdgcn_rcpf(sp.sf);
 }
 
-// h(v / s).  q1 below equals the IEEE float32 quotient v/s for every finite float16 v and every float16
-// s in [0x00A8, 0x70E2] (the clamped scale range) -- checked exhaustively on the CPU, see
-// tests/test_division_shortcut.py -- so rounding it to float16 is h(v / s).
-__device__ __forceinline__ half_t div_h(float vf, const SegP& sp) {
+// h(v / s) for finite v.  q1 rounds to the same float16 as the IEEE quotient v / s for every finite
+// float16 v, every float16 s in [0x00A8, 0x70E2] (the clamped scale range) and every r within 2 ulp of
+// 1/s -- checked exhaustively on the CPU (tests/test_division_shortcut.py); v_rcp_f32 is within 1 ulp.
+// The sign of a zero quotient is lost by the correction step: callers restore it from v.
+__device__ __forceinline__ float div_f(float vf, const SegP& sp) {
+  float q0 = vf * sp.r;
+  return __builtin_fmaf(__builtin_fmaf(-q0, sp.sf, vf), sp.r, q0);
+}
+// the same with +-0 and +-inf quotients handled (class mask: -inf | -0 | +0 | +inf)
+__device__ __forceinline__ half_t div_h_full(float vf, const SegP& sp) {
   float q0 = vf * sp.r;
   float q1 = __builtin_fmaf(__builtin_fmaf(-q0, sp.sf, vf), sp.r, q0);
-  // +-0 and +-inf quotients are already exact in q0; the correction step would turn -0 into +0 and
-  // inf into NaN (class mask: -inf | -0 | +0 | +inf)
   q1 = __builtin_amdgcn_classf(q0, 0x264) ? q0 : q1;
+  if (sp.sf != sp.sf) q1 = sp.sf;
   return (half_t)q1;
 }
 
-// Nearest value of an (E, M, bias) table for x given as float16 bits: round the 10-bit mantissa to M
-// bits (ties toward -inf: down in magnitude for x > 0, up for x < 0), saturate at the largest entry,
-// and below the smallest positive entry choose between it and 0 at their midpoint.  NaN -> +0.
+// amax: sign-cleared float16 bits
+__device__ __forceinline__ SegP params_absmax(uint32_t amax_bits, const QuantParams& p) {
+  SegP sp;
+  finish_params(sp, clamp_scale(div_qmax(h_from_bits(amax_bits), p)));
+  sp.zp = (half_t)0;
+  sp.slow = amax_bits >= 0x7c00u;  // inf or NaN in the segment
+  if (sp.slow) finish_params(sp, clamp_scale((half_t)((float)h_from_bits(amax_bits) / p.qmax)));
+  return sp;
+}
+// mm: min in the low half, max in the high half
+__device__ __forceinline__ SegP params_minmax(uint32_t mm, const QuantParams& p) {
+  SegP sp;
+  half_t rmin = h_from_bits(mm & 0xffffu), rmax = h_from_bits(mm >> 16);
+  half_t range = rmax - rmin;
+  finish_params(sp, clamp_scale(div_qmax(range, p)));
+  const half_t qmax_h = (half_t)p.qmax;
+  float nm = -(float)rmin;
+  half_t z = __builtin_rintf16(div_h_full(nm, sp));  // keeps the sign of a zero -rmin, as the reference does
+  z = z < (half_t)0 ? (half_t)0 : z;
+  z = z > qmax_h ? qmax_h : z;
+  sp.zp = z;
+  float big = __builtin_fmaxf(__builtin_fabsf((float)rmin), __builtin_fabsf((float)rmax));
+  // fast path needs finite data and |v / s| < 512 (exact integer rounding by the 1536 trick)
+  sp.slow = !(big * sp.r < 500.0f) || !((float)range < 65504.0f);
+  if (sp.slow) {
+    finish_params(sp, clamp_scale((half_t)((float)range / p.qmax)));
+    sp.r = 1.0f / sp.sf;
+    half_t zz = __builtin_rintf16(div_h_full(nm, sp));
+    zz = zz < (half_t)0 ? (half_t)0 : zz;
+    zz = zz > qmax_h ? qmax_h : zz;
+    sp.zp = zz;
+  }
+  return sp;
+}
+
+// Nearest value of an (E, M, bias) table for x given as float16 (or float32) bits: round the mantissa
+// to M bits (ties toward -inf: down in magnitude for x > 0, up for x < 0), saturate at the largest
+// entry, and below the smallest positive entry choose between it and 0 at their midpoint.  NaN -> +0.
 __device__ __forceinline__ uint32_t lut_round_bits(uint32_t xb, uint32_t signbit, uint32_t nanlimit, const LutConst& c) {
   uint32_t a = xb & (signbit - 1u);
   bool neg = (xb & signbit) != 0;
@@ -211,26 +293,129 @@ __device__ __forceinline__ uint32_t lut_round_bits(uint32_t xb, uint32_t signbit
   if (a > nanlimit) r = 0u;
   return r ? (r | (neg ? signbit : 0u)) : 0u;
 }
+// The same for two float16 values in one word, branch-free (no NaN handling: NaN segments are slow-path).
+__device__ __forceinline__ uint32_t lut_round_pk(uint32_t xw, const LutConst& c) {
+  uint32_t a = xw & 0x7fff7fffu;
+  uint32_t an = pk_add_u16(a, (xw >> 15) & 0x00010001u);  // a + 1 for negative x: turns '>=' into '>'
+  uint32_t r = pk_add_u16(an, dup16(c.half - 1u)) & dup16(0xffffu << c.shift);
+  r = pk_max_u16(pk_min_u16(r, dup16(c.maxb)), dup16(c.minpos));
+  uint32_t z = pk_sub_u16_sat(an, dup16(c.mid));  // nonzero iff |x| is past the 0 / minpos midpoint
+  uint32_t m = pk_sub_u16(0u, pk_min_u16(z, 0x00010001u));  // 0xffff or 0 per half
+  return ((xw & 0x80008000u) | r) & m;  // zero is +0
+}
 
 // ------------------------------------------------------------------------------------------------
-// one lane's 8 elements: quantize, dequantize, store, accumulate the error
+// one lane's 8 elements
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_abs_err(const QuantParams& p, const float* ae, int64_t e0) {
+  if (p.abs_err_f16) {
+    u32x4 a;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      h16x2 h = {(half_t)ae[2 * k], (half_t)ae[2 * k + 1]};
+      a[k] = as_u32(h) & 0x7fff7fffu;
+    }
+    *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0) = a;
+  } else {
+    f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
+    f32x4 a0 = {__builtin_fabsf(ae[0]), __builtin_fabsf(ae[1]), __builtin_fabsf(ae[2]), __builtin_fabsf(ae[3])};
+    f32x4 a1 = {__builtin_fabsf(ae[4]), __builtin_fabsf(ae[5]), __builtin_fabsf(ae[6]), __builtin_fabsf(ae[7])};
+    o[0] = a0;
+    o[1] = a1;
+  }
+}
+
+// Squares are rounded to float32 per element as numpy does (quant_error_multi_weight.py:57-58); a lane's
+// 8 squares (and 8 absolute errors) are summed pairwise in float32 -- at most 3 roundings, 1.8e-7
+// relative -- and every sum above that level is carried in float64.
+__device__ __forceinline__ void error_sums(const float* e, double& sse, double& sabs) {
+  float q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = e[i] * e[i];
+  float s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  float a = ((__builtin_fabsf(e[0]) + __builtin_fabsf(e[1])) + (__builtin_fabsf(e[2]) + __builtin_fabsf(e[3]))) +
+            ((__builtin_fabsf(e[4]) + __builtin_fabsf(e[5])) + (__builtin_fabsf(e[6]) + __builtin_fabsf(e[7])));
+  sse = (double)s;
+  sabs += (double)a;
+}
+
+// Fast path: packed float16 arithmetic, exact for finite data with |v / s| < 512.
+//  * rint(x) for |x| < 512 is (x + 1536) - 1536 in float16 (ulp 1 in [1024, 2048), round to nearest even);
+//    the low byte of the float16 bits of 1536 + q (0x6600 + q) is q's two's-complement byte.
+//  * symmetric: |v / s| <= qmax * (1 + 2^-11) < qmax + 0.5, so the clamp to +-qmax never acts.
 template <int FMT>
-__device__ __forceinline__ double process8(const QuantParams& p, u32x4 raw, const SegP& sp, int64_t e0,
+__device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
+                                              double& acc_abs) {
+  const uint32_t s2 = dup16(h_bits(sp.s)), zp2 = dup16(h_bits(sp.zp));
+  const h16x2 magic = as_h2(0x66006600u);  // 1536
+  u32x4 dq, cw;
+  float e[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t vw = raw[k];
+    const h16x2 vp = as_h2(vw);
+    const float v0 = (float)vp[0], v1 = (float)vp[1];
+    // (a zero quotient may come out as +0 here whatever the sign of v: see div_f)
+    const h16x2 x = {(half_t)div_f(v0, sp), (half_t)div_f(v1, sp)};
+    h16x2 d;
+    if constexpr (FMT == MQ_INT_SYM) {
+      h16x2 t = x + magic;
+      d = (t - magic) * as_h2(s2);
+      // q * s carries the sign of v, also when q is zero (rint(-0.3) is -0 in the reference)
+      d = as_h2((as_u32(d) & 0x7fff7fffu) | (vw & 0x80008000u));
+      cw[k] = as_u32(t);
+    } else if constexpr (FMT == MQ_INT_ASYM) {
+      // (q - zp) * s is +0 whenever it is zero, so no sign repair is needed here
+      h16x2 t = ((x + magic) - magic) + as_h2(zp2);
+      uint32_t tw = pk_min_f16(pk_max_f16(as_u32(t), 0u), dup16(h_bits((half_t)p.qmax)));
+      d = (as_h2(tw) - as_h2(zp2)) * as_h2(s2);
+      cw[k] = tw;
+    } else {
+      // the table's zero is +0 and a nonzero quotient has the right sign already
+      uint32_t qw = lut_round_pk(as_u32(x), p.lut);
+      d = as_h2(qw) * as_h2(s2);
+      cw[k] = qw;
+    }
+    dq[k] = as_u32(d);
+    e[2 * k] = v0 - (float)d[0];
+    e[2 * k + 1] = v1 - (float)d[1];
+  }
+  if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
+  if (p.codes) {
+    if constexpr (FMT == MQ_LUT_FP) {
+      *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = cw;
+    } else {
+      if constexpr (FMT == MQ_INT_ASYM) {
+        // integers 0..255 as float16: the low byte of the bits of 1024 + q is q
+        const h16x2 k1024 = as_h2(0x64006400u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cw[k] = as_u32(as_h2(cw[k]) + k1024);
+      }
+      u32x2 c = {__builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u), __builtin_amdgcn_perm(cw[3], cw[2], 0x06040200u)};
+      *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
+    }
+  }
+  double sse = 0.0;
+  if (p.need_err) {
+    if (p.abs_err) store_abs_err(p, e, e0);
+    error_sums(e, sse, acc_abs);
+  }
+  return sse;
+}
+
+// Slow path: the contract element by element (any float16 input, including inf / NaN / huge v / s).
+template <int FMT>
+__device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                            double& acc_abs) {
   const half_t qmax_h = (half_t)p.qmax;
-  u32x4 dq;          // 8 dequantized float16
-  u32x4 c16;         // LUT codes (float16 values)
-  uint32_t c8[2];    // INT codes (bytes)
-  float ae[8];
-  c8[0] = c8[1] = 0;
-  double sse = 0.0, sabs = 0.0;
+  u32x4 dq, c16;
+  uint32_t c8[2] = {0u, 0u};
+  float e[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     uint32_t vb = (i & 1) ? (raw[i >> 1] >> 16) : (raw[i >> 1] & 0xffffu);
     float vf = (float)h_from_bits(vb);
-    half_t x = div_h(vf, sp);
-    half_t d;
+    half_t x = div_h_full(vf, sp), d;
     uint32_t code;
     if constexpr (FMT == MQ_INT_SYM) {
       half_t q = __builtin_rintf16(x);
@@ -255,11 +440,7 @@ __device__ __forceinline__ double process8(const QuantParams& p, u32x4 raw, cons
     } else {
       c8[i >> 2] |= code << (8 * (i & 3));
     }
-    float err = vf - (float)d;
-    float sq = err * err;
-    ae[i] = __builtin_fabsf(err);
-    sse += (double)sq;
-    sabs += (double)ae[i];
+    e[i] = vf - (float)d;
   }
   if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
   if (p.codes) {
@@ -270,30 +451,27 @@ __device__ __forceinline__ double process8(const QuantParams& p, u32x4 raw, cons
       *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
     }
   }
-  if (p.abs_err) {
-    if (p.abs_err_f16) {
-      u32x4 a;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] = f2h_bits(ae[2 * k]) | (f2h_bits(ae[2 * k + 1]) << 16);
-      *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0) = a;
-    } else {
-      f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
-      f32x4 a0 = {ae[0], ae[1], ae[2], ae[3]}, a1 = {ae[4], ae[5], ae[6], ae[7]};
-      o[0] = a0;
-      o[1] = a1;
-    }
+  double sse = 0.0;
+  if (p.need_err) {
+    if (p.abs_err) store_abs_err(p, e, e0);
+    error_sums(e, sse, acc_abs);
   }
-  acc_abs += sabs;
   return sse;
+}
+
+template <int FMT>
+__device__ __forceinline__ double quant8(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
+                                         double& acc_abs) {
+  if (__builtin_expect(sp.slow, 0)) return quant8_slow<FMT>(p, raw, sp, e0, acc_abs);
+  return quant8_fast<FMT>(p, raw, sp, e0, acc_abs);
 }
 
 // quant_datatype's per-tensor float32 branch (quant_weight.py:562-575): x = w32 / s in float32, table
 // lookup in float32, (q * s) rounded to float32 and then to float16.
-__device__ __forceinline__ double process8_lut_f32(const QuantParams& p, const float* w32, u32x4 raw, float s,
-                                                   int64_t e0, double& acc_abs) {
+__device__ __forceinline__ double quant8_lut_f32(const QuantParams& p, const float* w32, u32x4 raw, float s,
+                                                 int64_t e0, double& acc_abs) {
   u32x4 dq, c16;
-  float ae[8];
-  double sse = 0.0, sabs = 0.0;
+  float e[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float x = w32[i] / s;
@@ -302,28 +480,15 @@ __device__ __forceinline__ double process8_lut_f32(const QuantParams& p, const f
     uint32_t db = f2h_bits(t), cb = f2h_bits(q);
     if (i & 1) { dq[i >> 1] |= db << 16; c16[i >> 1] |= cb << 16; } else { dq[i >> 1] = db; c16[i >> 1] = cb; }
     uint32_t vb = (i & 1) ? (raw[i >> 1] >> 16) : (raw[i >> 1] & 0xffffu);
-    float err = (float)h_from_bits(vb) - (float)h_from_bits(db);
-    float sq = err * err;
-    ae[i] = __builtin_fabsf(err);
-    sse += (double)sq;
-    sabs += (double)ae[i];
+    e[i] = (float)h_from_bits(vb) - (float)h_from_bits(db);
   }
   if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
   if (p.codes) *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = c16;
-  if (p.abs_err) {
-    if (p.abs_err_f16) {
-      u32x4 a;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] = f2h_bits(ae[2 * k]) | (f2h_bits(ae[2 * k + 1]) << 16);
-      *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0) = a;
-    } else {
-      f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
-      f32x4 a0 = {ae[0], ae[1], ae[2], ae[3]}, a1 = {ae[4], ae[5], ae[6], ae[7]};
-      o[0] = a0;
-      o[1] = a1;
-    }
+  double sse = 0.0;
+  if (p.need_err) {
+    if (p.abs_err) store_abs_err(p, e, e0);
+    error_sums(e, sse, acc_abs);
   }
-  acc_abs += sabs;
   return sse;
 }
 
@@ -344,10 +509,13 @@ __device__ __forceinline__ void block_partials(const QuantParams& p, double sse,
 }
 
 // ------------------------------------------------------------------------------------------------
-// SC_SUBWAVE: a segment is T <= 64 lanes of one wave; NV independent segments per lane in flight.
+// SC_SUBWAVE: a segment is T <= 64 lanes of one wave.  A wave streams NV x 1 KiB per iteration; the NV
+// vectors a lane holds belong to NV different segments.
 // ------------------------------------------------------------------------------------------------
 template <int FMT, int T, int NV>
-__device__ __forceinline__ void subwave_body(const QuantParams& p, double& acc_sse, double& acc_abs) {
+__global__ __launch_bounds__(256) void k_quant_team(QuantParams p) {
+  __shared__ double lds[32];
+  double acc_sse = 0.0, acc_abs = 0.0;
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
   constexpr int SPW = 64 / T;  // segments per wave per vector slot
@@ -355,66 +523,54 @@ __device__ __forceinline__ void subwave_body(const QuantParams& p, double& acc_s
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t tiles = (p.nseg + (int64_t)SPW * NV - 1) / ((int64_t)SPW * NV);
   const bool lane_in_seg = tl < p.vecs_per_seg;
+  // Software pipeline: the next tile's loads are issued before the current tile is computed, so a wave
+  // keeps 2 x NV KiB in flight.
+  u32x4 nxt[NV];
+  auto issue = [&](int64_t tile, u32x4* dst) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      int64_t sg = (tile * NV + j) * SPW + team;
+      dst[j] = (lane_in_seg && sg < p.nseg) ? load8_f16(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
+                                            : u32x4{0, 0, 0, 0};
+    }
+  };
+  if (gw < tiles) issue(gw, nxt);
   for (int64_t tile = gw; tile < tiles; tile += nwaves) {
     u32x4 raw[NV];
     bool valid[NV];
     int64_t seg[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
+      raw[j] = nxt[j];
       seg[j] = (tile * NV + j) * SPW + team;
       valid[j] = lane_in_seg && seg[j] < p.nseg;
-      raw[j] = valid[j] ? load8_f16(p.w, p.in_dtype, seg[j] * p.L + (int64_t)tl * 8) : u32x4{0, 0, 0, 0};
     }
-    SegP sp[NV];
-    if constexpr (FMT == MQ_INT_ASYM) {
-      half_t mn[NV], mx[NV];
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        minmax8(raw[j], mn[j], mx[j]);
-        if (!valid[j]) { mn[j] = h_from_bits(0x7c00u); mx[j] = h_from_bits(0xfc00u); }
-      }
-#pragma unroll
-      for (int j = 0; j < NV; ++j) team_minmax<T>(mn[j], mx[j]);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) sp[j] = params_minmax(mn[j], mx[j], p.qmax);
-    } else {
-      uint32_t m[NV];
-#pragma unroll
-      for (int j = 0; j < NV; ++j) m[j] = absmax8(raw[j]);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) m[j] = team_max_u32<T>(m[j]);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) sp[j] = params_absmax(m[j], p.qmax);
-    }
+    if (tile + nwaves < tiles) issue(tile + nwaves, nxt);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
+      SegP sp;
+      if constexpr (FMT == MQ_INT_ASYM) {
+        uint32_t lo, hi;
+        minmax8_pk(raw[j], lo, hi);
+        uint32_t mm = valid[j] ? fold_minmax(lo, hi) : 0xfc007c00u;  // (+inf, -inf): neutral
+        sp = params_minmax(team_reduce_u32<T>(mm, op_minmax), p);
+      } else {
+        uint32_t m = fold_max_u16(absmax8_pk(raw[j]));
+        sp = params_absmax(team_reduce_u32<T>(m, op_max_u32), p);
+      }
       double s = 0.0;
-      if (valid[j]) s = process8<FMT>(p, raw[j], sp[j], seg[j] * p.L + (int64_t)tl * 8, acc_abs);
+      const int64_t e0 = seg[j] * p.L + (int64_t)tl * 8;
+      if (valid[j]) s = quant8<FMT>(p, raw[j], sp, e0, acc_abs);
       acc_sse += s;
       if (p.seg_sse) {
         s = team_sum<T>(s);
         if (valid[j] && tl == 0) p.seg_sse[seg[j]] = s;
       }
       if (valid[j] && tl == 0) {
-        if (p.scale) p.scale[seg[j]] = (uint16_t)h_bits(sp[j].s);
-        if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg[j]] = (uint16_t)h_bits(sp[j].zp);
+        if (p.scale) p.scale[seg[j]] = (uint16_t)h_bits(sp.s);
+        if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg[j]] = (uint16_t)h_bits(sp.zp);
       }
     }
-  }
-}
-
-template <int FMT, int NV>
-__global__ __launch_bounds__(256) void k_quant_subwave(QuantParams p) {
-  __shared__ double lds[32];
-  double acc_sse = 0.0, acc_abs = 0.0;
-  switch (p.team_log2) {
-    case 0: subwave_body<FMT, 1, NV>(p, acc_sse, acc_abs); break;
-    case 1: subwave_body<FMT, 2, NV>(p, acc_sse, acc_abs); break;
-    case 2: subwave_body<FMT, 4, NV>(p, acc_sse, acc_abs); break;
-    case 3: subwave_body<FMT, 8, NV>(p, acc_sse, acc_abs); break;
-    case 4: subwave_body<FMT, 16, NV>(p, acc_sse, acc_abs); break;
-    case 5: subwave_body<FMT, 32, NV>(p, acc_sse, acc_abs); break;
-    default: subwave_body<FMT, 64, NV>(p, acc_sse, acc_abs); break;
   }
   block_partials(p, acc_sse, acc_abs, lds);
 }
@@ -432,59 +588,64 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
   const int tcount = BLOCK ? (int)blockDim.x : 64;
   uint32_t* lds_u = reinterpret_cast<uint32_t*>(lds + 32);  // [2][16] reduction exchange (BLOCK only)
   int parity = 0;
+  // Software pipeline (NV <= 8): the next segment's loads are issued before this one is computed.
+  constexpr bool PREFETCH = NV <= 8;
+  u32x4 nxt[PREFETCH ? NV : 1];
+  auto issue = [&](int64_t sg, u32x4* dst) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      int v = j * tcount + tid;
+      dst[j] = v < p.vecs_per_seg ? load8_f16(p.w, p.in_dtype, sg * p.L + (int64_t)v * 8) : u32x4{0, 0, 0, 0};
+    }
+  };
+  if constexpr (PREFETCH) {
+    if (first < p.nseg) issue(first, nxt);
+  }
   for (int64_t seg = first; seg < p.nseg; seg += stride) {
     const int64_t base = seg * p.L;
     u32x4 raw[NV];
     bool valid[NV];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      int v = j * tcount + tid;
-      valid[j] = v < p.vecs_per_seg;
-      raw[j] = valid[j] ? load8_f16(p.w, p.in_dtype, base + (int64_t)v * 8) : u32x4{0, 0, 0, 0};
+    for (int j = 0; j < NV; ++j) valid[j] = j * tcount + tid < p.vecs_per_seg;
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[j] = nxt[j];
+      if (seg + stride < p.nseg) issue(seg + stride, nxt);
+    } else {
+      issue(seg, raw);
     }
     SegP sp;
     if constexpr (FMT == MQ_INT_ASYM) {
-      half_t mn = h_from_bits(0x7c00u), mx = h_from_bits(0xfc00u);
+      uint32_t mm = 0xfc007c00u;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        half_t a, b;
-        minmax8(raw[j], a, b);
-        if (valid[j]) { mn = a < mn ? a : mn; mx = b > mx ? b : mx; }
+        uint32_t lo, hi;
+        minmax8_pk(raw[j], lo, hi);
+        if (valid[j]) mm = op_minmax(mm, fold_minmax(lo, hi));
       }
-      team_minmax<64>(mn, mx);
+      mm = team_reduce_u32<64>(mm, op_minmax);
       if constexpr (BLOCK) {
-        if (lane == 0) lds_u[parity * 16 + wv] = h_bits(mn) | (h_bits(mx) << 16);
+        if (lane == 0) lds_u[parity * 16 + wv] = mm;
         __syncthreads();
-        for (int i = 0; i < nw; ++i) {
-          uint32_t o = lds_u[parity * 16 + i];
-          half_t omn = h_from_bits(o & 0xffffu), omx = h_from_bits(o >> 16);
-          mn = omn < mn ? omn : mn;
-          mx = omx > mx ? omx : mx;
-        }
+        for (int i = 0; i < nw; ++i) mm = op_minmax(mm, lds_u[parity * 16 + i]);
       }
-      sp = params_minmax(mn, mx, p.qmax);
+      sp = params_minmax(mm, p);
     } else {
-      uint32_t m = 0;
+      uint32_t m2 = 0;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        uint32_t a = absmax8(raw[j]);
-        m = a > m ? a : m;
-      }
-      m = team_max_u32<64>(m);
+      for (int j = 0; j < NV; ++j) m2 = pk_max_u16(m2, absmax8_pk(raw[j]));
+      uint32_t m = team_reduce_u32<64>(fold_max_u16(m2), op_max_u32);
       if constexpr (BLOCK) {
         if (lane == 0) lds_u[parity * 16 + wv] = m;
         __syncthreads();
-        for (int i = 0; i < nw; ++i) {
-          uint32_t o = lds_u[parity * 16 + i];
-          m = o > m ? o : m;
-        }
+        for (int i = 0; i < nw; ++i) m = op_max_u32(m, lds_u[parity * 16 + i]);
       }
-      sp = params_absmax(m, p.qmax);
+      sp = params_absmax(m, p);
     }
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      if (valid[j]) s += process8<FMT>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc_abs);
+      if (valid[j]) s += quant8<FMT>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc_abs);
     acc_sse += s;
     if (p.seg_sse) {
       s = wave_sum(s);
@@ -550,7 +711,7 @@ __global__ __launch_bounds__(256) void k_tensor_reduce(QuantParams p, uint32_t* 
       }
     } else {
       u32x4 raw = load8_f16(p.w, p.in_dtype, v * 8);
-      uint32_t a = absmax8(raw);
+      uint32_t a = fold_max_u16(absmax8_pk(raw));
       amax = a > amax ? a : amax;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -560,9 +721,9 @@ __global__ __launch_bounds__(256) void k_tensor_reduce(QuantParams p, uint32_t* 
       }
     }
   }
-  amax = team_max_u32<64>(amax);
-  kmax = team_max_u32<64>(kmax);
-  uint32_t nkmin = team_max_u32<64>(0xffffu - kmin);
+  amax = team_reduce_u32<64>(amax, op_max_u32);
+  kmax = team_reduce_u32<64>(kmax, op_max_u32);
+  uint32_t nkmin = team_reduce_u32<64>(0xffffu - kmin, op_max_u32);
   if ((threadIdx.x & 63) == 0) {
     atomicMax(&tred[0], amax);
     atomicMax(&tred[1], kmax);
@@ -587,11 +748,13 @@ __global__ __launch_bounds__(256) void k_quant_tensor(QuantParams p) {
     s = s < 1e-5f ? 1e-5f : s;
     s = s > 1e4f ? 1e4f : s;
     s32 = s;
-    sp = finish_params((half_t)s);
+    finish_params(sp, (half_t)s);
+    sp.zp = (half_t)0;
+    sp.slow = false;
   } else if constexpr (FMT == MQ_INT_ASYM) {
-    sp = params_minmax(h_from_bits(h_unkey(0xffffu - p.tred[2])), h_from_bits(h_unkey(p.tred[1])), p.qmax);
+    sp = params_minmax(h_unkey(0xffffu - p.tred[2]) | (h_unkey(p.tred[1]) << 16), p);
   } else {
-    sp = params_absmax(p.tred[0], p.qmax);
+    sp = params_absmax(p.tred[0], p);
   }
   for (int64_t tile = gw; tile < tiles; tile += nwaves) {
     u32x4 raw[NV];
@@ -609,9 +772,9 @@ __global__ __launch_bounds__(256) void k_quant_tensor(QuantParams p) {
       if (FMT == MQ_LUT_FP && p.f32_math) {
         float w32[8];
         load8_f32(p.w, p.in_dtype, e0, w32);
-        acc_sse += process8_lut_f32(p, w32, raw[j], s32, e0, acc_abs);
+        acc_sse += quant8_lut_f32(p, w32, raw[j], s32, e0, acc_abs);
       } else {
-        acc_sse += process8<FMT>(p, raw[j], sp, e0, acc_abs);
+        acc_sse += quant8<FMT>(p, raw[j], sp, e0, acc_abs);
       }
     }
   }
@@ -642,33 +805,27 @@ __global__ __launch_bounds__(256) void k_quant_generic(QuantParams p) {
   int parity = 0;
   for (int64_t seg = blockIdx.x; seg < p.nseg; seg += gridDim.x) {
     const int64_t base = seg * p.L;
-    uint32_t m = 0;
-    half_t mn = h_from_bits(0x7c00u), mx = h_from_bits(0xfc00u);
+    uint32_t m = 0, mm = 0xfc007c00u;
     for (int64_t i = threadIdx.x; i < p.L; i += blockDim.x) {
       uint32_t vb = load1_f16(p.w, p.in_dtype, base + i);
-      uint32_t a = vb & 0x7fffu;
-      m = a > m ? a : m;
-      half_t v = h_from_bits(vb);
-      mn = v < mn ? v : mn;
-      mx = v > mx ? v : mx;
+      m = op_max_u32(m, vb & 0x7fffu);
+      mm = op_minmax(mm, dup16(vb));
     }
-    m = team_max_u32<64>(m);
-    team_minmax<64>(mn, mx);
-    if (lane == 0) { lds_u[parity * 32 + wv] = m; lds_u[parity * 32 + 16 + wv] = h_bits(mn) | (h_bits(mx) << 16); }
+    m = team_reduce_u32<64>(m, op_max_u32);
+    mm = team_reduce_u32<64>(mm, op_minmax);
+    if (lane == 0) { lds_u[parity * 32 + wv] = m; lds_u[parity * 32 + 16 + wv] = mm; }
     __syncthreads();
     for (int i = 0; i < nw; ++i) {
-      uint32_t o = lds_u[parity * 32 + i], o2 = lds_u[parity * 32 + 16 + i];
-      m = o > m ? o : m;
-      half_t omn = h_from_bits(o2 & 0xffffu), omx = h_from_bits(o2 >> 16);
-      mn = omn < mn ? omn : mn;
-      mx = omx > mx ? omx : mx;
+      m = op_max_u32(m, lds_u[parity * 32 + i]);
+      mm = op_minmax(mm, lds_u[parity * 32 + 16 + i]);
     }
-    SegP sp = (FMT == MQ_INT_ASYM) ? params_minmax(mn, mx, p.qmax) : params_absmax(m, p.qmax);
+    SegP sp = (FMT == MQ_INT_ASYM) ? params_minmax(mm, p) : params_absmax(m, p);
+    sp.r = 1.0f / sp.sf;
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < p.L; i += blockDim.x) {
       uint32_t vb = load1_f16(p.w, p.in_dtype, base + i);
       float vf = (float)h_from_bits(vb);
-      half_t x = div_h(vf, sp), d;
+      half_t x = div_h_full(vf, sp), d;
       uint32_t code;
       if constexpr (FMT == MQ_INT_SYM) {
         half_t q = __builtin_rintf16(x);
@@ -764,10 +921,50 @@ static bool lut_consts(const mq_quant_cfg* cfg, bool f32, LutConst* c, float* lu
   return true;
 }
 
+// float16 value of a bit pattern, on the host
+static float host_h2f(uint32_t h) {
+  uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+  float v = e == 0 ? ldexpf((float)m, -24) : ldexpf((float)(m | 1024u), (int)e - 25);
+  return (h & 0x8000u) ? -v : v;
+}
+// Does a * RN(1/c), corrected once by the fma residual, equal a / c for every finite float16 a >= 0?
+// (31 744 cases; the answer is cached per constant by the caller.)
+static bool recip_division_exact(float c) {
+  const float r = 1.0f / c;
+  for (uint32_t b = 0; b < 0x7c00u; ++b) {
+    float a = host_h2f(b), q0 = a * r;
+    float q1 = __builtin_fmaf(__builtin_fmaf(-q0, c, a), r, q0);
+    if (q1 != a / c) return false;
+  }
+  return true;
+}
+static bool recip_ok_cached(float c) {
+  static thread_local float known_c[8];
+  static thread_local int known_ok[8], nknown = 0;
+  for (int i = 0; i < nknown; ++i)
+    if (known_c[i] == c) return known_ok[i] != 0;
+  bool ok = recip_division_exact(c);
+  if (nknown < 8) { known_c[nknown] = c; known_ok[nknown] = ok; ++nknown; }
+  return ok;
+}
+
+template <int FMT, int NV>
+static void launch_team(int team_log2, dim3 grid, hipStream_t st, const QuantParams& p) {
+  switch (team_log2) {
+    case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV>), grid, dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((k_quant_team<FMT, 2, NV>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((k_quant_team<FMT, 4, NV>), grid, dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((k_quant_team<FMT, 8, NV>), grid, dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((k_quant_team<FMT, 16, NV>), grid, dim3(256), 0, st, p); break;
+    case 5: hipLaunchKernelGGL((k_quant_team<FMT, 32, NV>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((k_quant_team<FMT, 64, NV>), grid, dim3(256), 0, st, p); break;
+  }
+}
+
 template <int FMT>
-static void launch_fmt(int scope, int nv, int threads, dim3 grid, hipStream_t st, const QuantParams& p) {
+static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, hipStream_t st, const QuantParams& p) {
   if (scope == SC_SUBWAVE) {
-    hipLaunchKernelGGL((k_quant_subwave<FMT, 4>), grid, dim3(256), 0, st, p);
+    launch_team<FMT, 4>(team_log2, grid, st, p);
   } else if (scope == SC_TENSOR) {
     hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
   } else if (scope == SC_WAVE) {
@@ -791,6 +988,18 @@ static void launch_fmt(int scope, int nv, int threads, dim3 grid, hipStream_t st
 }
 
 static const size_t kWsHeader = 256;  // reduction words, kept apart from the partials
+
+// Upper bound on the grid of the streaming kernels, in 256-thread workgroups.  4 per CU keeps every
+// wave looping over several tiles so that its prefetch overlaps its compute.  MQ_MAX_BLOCKS overrides
+// it for tuning runs.
+static int64_t grid_cap() {
+  static const int64_t cap = [] {
+    const char* e = getenv("MQ_MAX_BLOCKS");
+    int64_t v = e ? atoll(e) : 1024;
+    return v < 1 ? 1 : (v > MQ_MAX_GRID ? MQ_MAX_GRID : v);
+  }();
+  return cap;
+}
 
 extern "C" size_t mq_quantize_workspace_bytes(int64_t, int64_t, const mq_quant_cfg*) {
   return kWsHeader + (size_t)MQ_MAX_GRID * 2 * sizeof(double);
@@ -821,6 +1030,8 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
   if (cfg->format == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
   else if (cfg->format == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
   else if (!lut_consts(cfg, cfg->f32_math != 0, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
+  p.rqmax = 1.0f / p.qmax;
+  p.qmax_recip_ok = recip_ok_cached(p.qmax);
   p.deq = static_cast<uint16_t*>(out->deq);
   p.codes = out->codes;
   p.scale = static_cast<uint16_t*>(out->scale);
@@ -828,6 +1039,7 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
   p.abs_err = out->abs_err;
   p.abs_err_f16 = out->abs_err_dtype == MQ_F16;
   p.seg_sse = out->seg_sse;
+  p.need_err = (out->abs_err || out->seg_sse || out->totals) ? 1 : 0;
   uint32_t* tred = static_cast<uint32_t*>(workspace);
   p.tred = tred;
   p.partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kWsHeader);
@@ -841,7 +1053,7 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
     return MQ_ERR_ALIGN;
   const bool vec_ok = (p.L % 8 == 0) && al(w, 16) && al(out->deq, 16) && al(out->codes, 16) && al(out->abs_err, 16);
 
-  int scope, nv = 4, threads = 256;
+  int scope, nv = 4, threads = 256, team_log2 = 0;
   int64_t work_blocks;
   p.vecs_per_seg = (int32_t)(p.L / 8 > INT32_MAX ? INT32_MAX : p.L / 8);
   if (cfg->group_size == -1 && vec_ok) {
@@ -853,8 +1065,8 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
     work_blocks = p.nseg;
   } else if (p.L / 8 <= 64) {
     scope = SC_SUBWAVE;
-    p.team_log2 = ilog2_ceil(p.L / 8);
-    int64_t spw = 64 >> p.team_log2;
+    team_log2 = ilog2_ceil(p.L / 8);
+    int64_t spw = 64 >> team_log2;
     int64_t tiles = (p.nseg + spw * 4 - 1) / (spw * 4);
     work_blocks = (tiles + 3) / 4;
   } else if (p.L / 8 <= 1024) {
@@ -867,7 +1079,7 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
     nv = (p.L / 8 + threads - 1) / threads <= 8 ? 8 : 16;
     work_blocks = p.nseg;
   }
-  int64_t max_grid = threads == 1024 ? MQ_MAX_GRID / 4 : MQ_MAX_GRID;
+  int64_t max_grid = scope == SC_BLOCK || scope == -1 ? (threads == 1024 ? MQ_MAX_GRID / 4 : MQ_MAX_GRID) : grid_cap();
   dim3 grid((unsigned)(work_blocks < max_grid ? work_blocks : max_grid));
 
   if (scope == SC_TENSOR) {
@@ -876,9 +1088,9 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
     hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < MQ_MAX_GRID ? rb : MQ_MAX_GRID)), dim3(256), 0, st, p, tred);
   }
   switch (cfg->format) {
-    case MQ_INT_SYM: launch_fmt<MQ_INT_SYM>(scope, nv, threads, grid, st, p); break;
-    case MQ_INT_ASYM: launch_fmt<MQ_INT_ASYM>(scope, nv, threads, grid, st, p); break;
-    default: launch_fmt<MQ_LUT_FP>(scope, nv, threads, grid, st, p); break;
+    case MQ_INT_SYM: launch_fmt<MQ_INT_SYM>(scope, nv, threads, team_log2, grid, st, p); break;
+    case MQ_INT_ASYM: launch_fmt<MQ_INT_ASYM>(scope, nv, threads, team_log2, grid, st, p); break;
+    default: launch_fmt<MQ_LUT_FP>(scope, nv, threads, team_log2, grid, st, p); break;
   }
   MQ_HIP(hipGetLastError());
   if (out->totals || (scope == SC_TENSOR && out->seg_sse)) {

@@ -1,7 +1,7 @@
 """GPU: the HIP quantize path (through the C ABI, via the reference-shaped Python API) against the
 golden vectors and against the CPU oracle on seeded inputs.  Bit-exact for codes, scales, zero-points,
-dequantized values and element-wise errors; sums of squares within 1e-12 relative of a float64 sum of
-the same float32 squares."""
+dequantized values and element-wise errors; sums of squares within 2e-7 relative of a float64 sum of
+the same float32 squares (and within float64 rounding of the kernel's documented summation scheme)."""
 import numpy as np
 import pytest
 import torch
@@ -159,13 +159,29 @@ def test_vs_oracle_shapes(qa, oracle, fmt, dt):
             d32 = exp["deq"].view(np.float16).astype(np.float32)
             err = v32 - d32
             assert np.array_equal(res.abs_err.cpu().numpy().view(np.uint32), np.abs(err).view(np.uint32)), what
-            sq = (err * err).astype(np.float64)
             L = rows * cols if gs == -1 else (cols if (gs is None or gs <= 0) else gs)
-            seg = sq.reshape(-1, L).sum(axis=1)
-            np.testing.assert_allclose(res.seg_sse.cpu().numpy(), seg, rtol=1e-12, atol=0, err_msg=what)
+            sq32, ab32 = err * err, np.abs(err)
             tot = res.totals.cpu().numpy()
-            np.testing.assert_allclose(tot[0], sq.sum(), rtol=1e-12, err_msg=what)
-            np.testing.assert_allclose(tot[1], np.abs(err).astype(np.float64).sum(), rtol=1e-12, err_msg=what)
+            got_seg = res.seg_sse.cpu().numpy()
+            # (a) against a float64 sum of the float32 squares: within the documented 2e-7
+            np.testing.assert_allclose(got_seg, sq32.astype(np.float64).reshape(-1, L).sum(axis=1), rtol=2e-7,
+                                       atol=0, err_msg=what)
+            np.testing.assert_allclose(tot[0], sq32.astype(np.float64).sum(), rtol=2e-7, err_msg=what)
+            np.testing.assert_allclose(tot[1], ab32.astype(np.float64).sum(), rtol=2e-7, err_msg=what)
+            # (b) against the kernel's own summation scheme (a lane's 8 values pairwise in float32, float64
+            #     above; the scalar fallback sums every element in float64): equal up to float64 rounding
+            if L % 8 == 0 and L // 8 <= 16384:
+                def lane_sums(a):
+                    a = a.reshape(-1, 8)
+                    return (((a[:, 0] + a[:, 1]) + (a[:, 2] + a[:, 3])) +
+                            ((a[:, 4] + a[:, 5]) + (a[:, 6] + a[:, 7]))).astype(np.float64)
+                psq, pab = lane_sums(sq32), lane_sums(ab32)
+            else:
+                psq, pab = sq32.astype(np.float64).reshape(-1), ab32.astype(np.float64).reshape(-1)
+            np.testing.assert_allclose(got_seg, psq.reshape(got_seg.size, -1).sum(axis=1), rtol=1e-12, atol=0,
+                                       err_msg=what)
+            np.testing.assert_allclose(tot[0], psq.sum(), rtol=1e-12, err_msg=what)
+            np.testing.assert_allclose(tot[1], pab.sum(), rtol=1e-12, err_msg=what)
             # float16 error variant (single_weight_quant_error.py:39-40)
             res16 = qa.quantize(wd, fmt_code, 8, gs, fmt if fmt_code == _lib.LUT_FP else None,
                                 deq=False, codes=False, scale=False, abs_err=torch.float16)

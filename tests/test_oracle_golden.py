@@ -73,7 +73,8 @@ def test_software_half_conversion(oracle):
     bits = np.arange(65536, dtype=np.uint16)
     f = bits.view(np.float16).astype(np.float32)
     for b in range(0, 65536, 7):
-        x = L.orc_h2f(b)
+        x = L.orc_h2f_soft(b)
+        assert L.orc_h2f(b) == x or np.isnan(x)
         if np.isnan(f[b]):
             assert np.isnan(x)
         else:
@@ -84,7 +85,7 @@ def test_software_half_conversion(oracle):
                                        np.inf, -np.inf], np.float32)])
     want = xs.astype(np.float16).view(np.uint16)
     for x, wv in zip(xs, want):
-        assert L.orc_f2h(float(x)) == wv
+        assert L.orc_f2h_soft(float(x)) == wv and L.orc_f2h(float(x)) == wv
 
 
 def _digest(a):
