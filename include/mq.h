@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-typedef enum { MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2 } mq_dtype;
+typedef enum { MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2, MQ_F64 = 3 } mq_dtype;
 
 /* Quantization formats of the hot path. */
 typedef enum {
@@ -83,6 +83,59 @@ size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cf
  */
 int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
                 const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Bytes of device workspace mq_percentile needs (histograms + selection state). */
+size_t mq_percentile_workspace_bytes(void);
+
+/*
+ * np.percentile(x, pct) with the default 'linear' method for a NON-NEGATIVE float32 (MQ_F32) or float64
+ * (MQ_F64) array of n values in device memory (the sign bit is ignored), computed exactly by radix
+ * select on the float bit patterns: 2 passes over a float32 array, 4 over a float64 one.  Replaces
+ *   np.percentile(abs_err, 99)  elwise_error/onnx_error_cli.py:113-114   (float32, K*C values)
+ *   np.percentile(vec, 99)      MSE&P99/quant_error_multi_weight.py:85, quant_error_single_weight.py:79
+ *                               (float64 per-vector MSE list)
+ * The virtual index, its floor and the interpolation follow numpy 2.2 in the array's dtype, so the result
+ * has the same bits as numpy's.  out (one value) and out_pair (the two order statistics interpolated
+ * between) are device pointers of the array's dtype; either may be NULL.  x must be 16-byte aligned.
+ */
+int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
+                  void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Bytes of device workspace mq_error_stats needs (want_cols: column sums requested). */
+size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t want_cols);
+
+/*
+ * Error statistics between two stored row-major [rows, cols] tensors a (baseline) and b (quantized), both
+ * float16 or both float32, as the analysis scripts compute them from the two ONNX initializers:
+ *   totals[0] = sum (a32-b32)^2, totals[1] = sum |a32-b32|   compute_mse, quant_error_multi_weight.py:55-58;
+ *                                                           get_error_sum, onnx_error_cli.py:116-117
+ *   seg_sse[s]  row-form sums over consecutive runs of seg_len elements (rows, or (row, group) pairs in
+ *               row-major order)                            quant_error_single_weight.py:56-71
+ *   col_sse[c]  per-column sums over all rows (column blocks are sums of these)
+ *                                                           quant_error_multi_weight.py:67-78
+ *   abs_err     |a32 - b32| as float32 (onnx_error_cli.py:90-91) or, for float16 inputs, the float16
+ *               |h(a - b)| of single_weight_quant_error.py:39-40 and compare.py:104
+ * Divide by the vector length on the host side to get the MSEs.  Any output may be NULL.
+ */
+int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,
+                   void* abs_err, int32_t abs_err_dtype, double* seg_sse, double* col_sse, double* totals,
+                   void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
+ * idx[i] = min(np.digitize(abs_err[i], bins, right=True), nbins - 1) for a float16 |error| array
+ * (elwise_error/single_weight_quant_error.py:43-51).  bins: host array of nbins <= 64 ascending float64.
+ */
+int mq_bucketize_f16(const void* abs_err_f16, int64_t n, const double* bins_host, int32_t nbins, uint8_t* idx,
+                     void* hip_stream);
+
+/*
+ * elwise_error/compare.py:99-125 for nfmt <= 7 quantized float16 tensors q_f16[f] of one float16 baseline:
+ * e_f = |h(w - q_f)|, m = min_f e_f, flags[i] bit 7 = (m > threshold), bit f = (e_f == m) and not bit 7.
+ * threshold_f16_bits: the threshold rounded to float16 (numpy compares a float16 array with a Python
+ * float in float16).  min_err_f16 (optional) receives m.  q_f16 is a HOST array of device pointers.
+ */
+int mq_compare_formats_f16(const void* w_f16, const void* const* q_f16, int32_t nfmt, int64_t n,
+                           uint16_t threshold_f16_bits, uint8_t* flags, void* min_err_f16, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,262 @@
+// Exact percentiles of non-negative float arrays on gfx950 (MI355X): radix select on the float bit
+// patterns instead of a sort.
+//
+// Replaces np.percentile(x, p) (method 'linear') as the reference's analysis scripts call it:
+//   elwise_error/onnx_error_cli.py:113-114        P99 of the float32 |error| array (K*C values)
+//   MSE&P99/quant_error_multi_weight.py:85         P99 of the float64 per-vector MSE list
+//   MSE&P99/quant_error_single_weight.py:79        the same, row form
+//
+// The bits of a non-negative IEEE float order like unsigned integers.  Keys are widened to 63 bits
+// (float32 bits << 32) and resolved most-significant digit first:
+//   level 0: 15 bits, histogram of EVERY element in LDS (32 768 x u32 = 128 KiB, one 1024-thread
+//            workgroup per CU), merged into a global histogram with one atomic per non-empty bin;
+//   level 1..3: 16 bits each, only elements whose higher bits match the prefix found so far take part
+//            (a fraction of a percent); each workgroup aggregates them in a small LDS hash table before
+//            touching the global histogram, so heavy duplicates cost no global atomic traffic.
+// A float32 array needs levels 0 and 1 -- two passes over the data; float64 needs four.
+// Both order statistics numpy interpolates between (ranks k and k + 1) are tracked, each with its own
+// prefix once they part.  The final interpolation repeats numpy 2.2's arithmetic in the array's dtype.
+#include "mq_common.h"
+
+#define SEL_TOP_BINS 32768
+#define SEL_DIGIT_BINS 65536
+#define SEL_HASH 2048
+
+struct SelState {
+  uint64_t prefix[2];  // resolved high bits of the two keys, left-aligned in 63 bits
+  uint64_t rank[2];    // remaining rank inside the current prefix
+  int32_t same;        // 1 while both ranks share one prefix
+  int32_t pad;
+};
+
+struct SelWs {
+  SelState st;
+  uint32_t pad[48];
+  uint32_t top[SEL_TOP_BINS];
+  uint32_t digit[2][SEL_DIGIT_BINS];
+};
+
+__device__ __forceinline__ uint64_t key_of(float v) { return (uint64_t)(f_bits(v) & 0x7fffffffu) << 32; }
+__device__ __forceinline__ uint64_t key_of(double v) { return __builtin_bit_cast(uint64_t, v) & 0x7fffffffffffffffull; }
+
+// ---- level 0 -------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sel_hist_top(const T* x, int64_t n, uint32_t* ghist) {
+  extern __shared__ uint32_t lh[];
+  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
+  const int64_t nvec = n / V;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = t0; v < nvec; v += step) {
+    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&lh[(raw[i] >> 16) & 0x7fffu], 1u);
+    } else {
+      atomicAdd(&lh[(raw[1] >> 16) & 0x7fffu], 1u);
+      atomicAdd(&lh[(raw[3] >> 16) & 0x7fffu], 1u);
+    }
+  }
+  for (int64_t i = nvec * V + t0; i < n; i += step) atomicAdd(&lh[(uint32_t)(key_of(x[i]) >> 48)], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) {
+    uint32_t c = lh[i];
+    if (c) atomicAdd(&ghist[i], c);
+  }
+}
+
+// ---- scan of a histogram: which bin holds each remaining rank --------------------------------------
+// One 1024-thread workgroup.  nbins is 32 768 (level 0) or 65 536; shift is the bit position of the digit.
+__global__ __launch_bounds__(1024) void k_sel_scan(SelWs* ws, int level) {
+  __shared__ uint64_t part[1024];
+  __shared__ SelState st, res;
+  const int nbins = level == 0 ? SEL_TOP_BINS : SEL_DIGIT_BINS;
+  const int shift = 48 - 16 * level;
+  const int per = nbins / 1024;
+  if (threadIdx.x == 0) { st = ws->st; res = ws->st; }
+  __syncthreads();
+  const bool shared_hist = level == 0 || st.same;
+  const int nsel = shared_hist ? 1 : 2;
+  for (int s = 0; s < nsel; ++s) {
+    const uint32_t* h = level == 0 ? ws->top : ws->digit[s];
+    uint64_t sum = 0;
+    for (int i = 0; i < per; ++i) sum += h[threadIdx.x * per + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    // inclusive scan of the 1024 partial sums (Hillis-Steele)
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint64_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const uint64_t before = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    // ranks to place against this histogram: both while they share it, else rank s only
+    for (int r = 0; r < 2; ++r) {
+      if (!shared_hist && r != s) continue;
+      const uint64_t rk = st.rank[r];
+      if (rk >= before && rk < part[threadIdx.x]) {  // exactly one thread owns the rank
+        uint64_t acc = before;
+        for (int i = 0; i < per; ++i) {
+          uint32_t c = h[threadIdx.x * per + i];
+          if (rk < acc + c) {
+            res.prefix[r] = st.prefix[r] | ((uint64_t)(threadIdx.x * per + i) << shift);
+            res.rank[r] = rk - acc;
+            break;
+          }
+          acc += c;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    res.same = res.prefix[0] == res.prefix[1] ? 1 : 0;
+    ws->st = res;
+  }
+}
+
+// ---- levels 1..3 -----------------------------------------------------------------------------------
+// Elements whose bits above the digit equal a tracked prefix are counted per digit value; a workgroup
+// first aggregates them in an LDS hash table (linear probing), then merges the table into the global
+// histogram.  A full table (more distinct values than slots) falls back to global atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void k_sel_hist_digit(const T* x, int64_t n, SelWs* ws, int level) {
+  __shared__ uint32_t hkey[2][SEL_HASH];  // digit + 1, 0 = empty
+  __shared__ uint32_t hcnt[2][SEL_HASH];
+  for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) { (&hkey[0][0])[i] = 0; (&hcnt[0][0])[i] = 0; }
+  __syncthreads();
+  const int shift = 48 - 16 * level;
+  const uint64_t himask = ~((1ull << (shift + 16)) - 1ull) & 0x7fffffffffffffffull;
+  const uint64_t p0 = ws->st.prefix[0], p1 = ws->st.prefix[1];
+  const bool same = ws->st.same != 0;
+  auto put = [&](uint64_t key) {
+    const uint64_t hi = key & himask;
+    const bool m0 = hi == (p0 & himask), m1 = !same && hi == (p1 & himask);
+    if (!(m0 || m1)) return;
+    const int s = m0 ? 0 : 1;
+    const uint32_t d = (uint32_t)(key >> shift) & 0xffffu;
+    uint32_t h = (d * 2654435761u) >> 21;  // 11 bits
+    for (int probe = 0; probe < 64; ++probe) {
+      uint32_t old = atomicCAS(&hkey[s][h], 0u, d + 1u);
+      if (old == 0u || old == d + 1u) { atomicAdd(&hcnt[s][h], 1u); return; }
+      h = (h + 1) & (SEL_HASH - 1);
+    }
+    atomicAdd(&ws->digit[s][d], 1u);
+  };
+  constexpr int V = 16 / sizeof(T);
+  const int64_t nvec = n / V;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = t0; v < nvec; v += step) {
+    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) put((uint64_t)(raw[i] & 0x7fffffffu) << 32);
+    } else {
+      put((((uint64_t)raw[1] << 32) | raw[0]) & 0x7fffffffffffffffull);
+      put((((uint64_t)raw[3] << 32) | raw[2]) & 0x7fffffffffffffffull);
+    }
+  }
+  for (int64_t i = nvec * V + t0; i < n; i += step) put(key_of(x[i]));
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) {
+    const int s = i / SEL_HASH, h = i % SEL_HASH;
+    if (hkey[s][h]) atomicAdd(&ws->digit[s][hkey[s][h] - 1u], hcnt[s][h]);
+  }
+}
+
+__global__ void k_sel_clear_digits(SelWs* ws) {
+  uint32_t* d = &ws->digit[0][0];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * SEL_DIGIT_BINS; i += gridDim.x * blockDim.x) d[i] = 0;
+}
+__global__ void k_sel_init(SelWs* ws, uint64_t k0, uint64_t k1) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SEL_TOP_BINS; i += gridDim.x * blockDim.x) ws->top[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    SelState s = {};
+    s.rank[0] = k0;
+    s.rank[1] = k1;
+    s.same = 1;
+    ws->st = s;
+  }
+}
+
+// ---- interpolation: numpy's _lerp (lib/_function_base_impl.py) in the array's dtype ----------------
+//   r = a + (b - a) * t;  where t >= 0.5:  r = b - (b - a) * (1 - t)
+template <typename T>
+__global__ void k_sel_finish(const SelWs* ws, T gamma, T* out, T* out_pair) {
+  T a, b;
+  if constexpr (sizeof(T) == 4) {
+    a = f_from_bits((uint32_t)(ws->st.prefix[0] >> 32));
+    b = f_from_bits((uint32_t)(ws->st.prefix[1] >> 32));
+  } else {
+    a = __builtin_bit_cast(double, ws->st.prefix[0]);
+    b = __builtin_bit_cast(double, ws->st.prefix[1]);
+  }
+  T diff = b - a;
+  T r = a + diff * gamma;
+  if (gamma >= (T)0.5) r = b - diff * ((T)1 - gamma);
+  if (out) *out = r;
+  if (out_pair) { out_pair[0] = a; out_pair[1] = b; }
+}
+
+// ================================================================================================
+extern "C" size_t mq_percentile_workspace_bytes(void) { return sizeof(SelWs); }
+
+template <typename T>
+static int run_select(const T* x, int64_t n, int64_t k0, int64_t k1, T gamma, T* out, T* out_pair, SelWs* ws,
+                      hipStream_t st) {
+  MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<T>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
+  hipLaunchKernelGGL(k_sel_init, dim3(32), dim3(256), 0, st, ws, (uint64_t)k0, (uint64_t)k1);
+  constexpr int V = 16 / sizeof(T);
+  int64_t nb = (n / V + 1024 * 4 - 1) / (1024 * 4);
+  unsigned grid_top = (unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+  hipLaunchKernelGGL((k_sel_hist_top<T>), dim3(grid_top), dim3(1024), SEL_TOP_BINS * 4, st, x, n, ws->top);
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, ws, 0);
+  const int levels = sizeof(T) == 4 ? 1 : 3;
+  int64_t nb2 = (n / V + 256 * 4 - 1) / (256 * 4);
+  unsigned grid_d = (unsigned)(nb2 < 1 ? 1 : (nb2 > 1024 ? 1024 : nb2));
+  for (int level = 1; level <= levels; ++level) {
+    hipLaunchKernelGGL(k_sel_clear_digits, dim3(128), dim3(256), 0, st, ws);
+    hipLaunchKernelGGL((k_sel_hist_digit<T>), dim3(grid_d), dim3(256), 0, st, x, n, ws, level);
+    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, ws, level);
+  }
+  hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(1), 0, st, ws, gamma, out, out_pair);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+// np.percentile(x, pct) for a non-negative float32 / float64 array in device memory (the sign bit is
+// ignored, i.e. the percentile of |x| is returned).  The virtual index (n - 1) * (pct / 100), its floor
+// and the interpolation weight are computed in the array's dtype, as numpy 2.2 does.
+extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
+                             void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!x || n <= 0 || !(pct >= 0.0 && pct <= 100.0) || (!out && !out_pair)) return MQ_ERR_ARG;
+  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(workspace) % 16) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  SelWs* ws = static_cast<SelWs*>(workspace);
+  int64_t k0, k1;
+  if (dtype == MQ_F32) {
+    float q = (float)pct / 100.0f;          // np.true_divide(q, float32(100))
+    float vi = (float)(n - 1) * q;           // (n - 1) * quantiles, float32
+    float prev = __builtin_floorf(vi);
+    float gamma = vi - prev;
+    k0 = (int64_t)prev; k1 = k0 + 1;
+    if (vi >= (float)(n - 1)) { k0 = k1 = n - 1; }
+    if (k1 > n - 1) k1 = n - 1;
+    return run_select<float>(static_cast<const float*>(x), n, k0, k1, gamma, static_cast<float*>(out),
+                             static_cast<float*>(out_pair), ws, st);
+  }
+  double q = pct / 100.0;
+  double vi = (double)(n - 1) * q;
+  double prev = __builtin_floor(vi);
+  double gamma = vi - prev;
+  k0 = (int64_t)prev; k1 = k0 + 1;
+  if (vi >= (double)(n - 1)) { k0 = k1 = n - 1; }
+  if (k1 > n - 1) k1 = n - 1;
+  return run_select<double>(static_cast<const double*>(x), n, k0, k1, gamma, static_cast<double*>(out),
+                            static_cast<double*>(out_pair), ws, st);
+}

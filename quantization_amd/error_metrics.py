@@ -1,0 +1,239 @@
+"""Error analysis on the device: the arithmetic of the reference's MSE&P99/ and elwise_error/ scripts,
+taking the two tensors those scripts read from the baseline and quantized ONNX files.
+
+Citations are into /root/reference.  Every function takes ROCm tensors (host tensors are moved to the
+current device) and runs the HIP kernels behind include/mq.h: mq_error_stats, mq_percentile,
+mq_bucketize_f16, mq_compare_formats_f16.  Sums of squares are carried in float64 (the scripts use
+numpy's float32 pairwise mean), so MSE values agree with the scripts to ~1e-7 relative, not bit for bit;
+percentiles of a given array, element-wise errors, bucket indices and masks are bit-exact.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fused import require_device, workspace
+
+_DT = {torch.float16: _lib.F16, torch.float32: _lib.F32, torch.float64: 3}
+
+
+def _bind():
+    L = _lib.lib()
+    if getattr(L, "_err_bound", False):
+        return L
+    vp, i64, i32, sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t
+    L.mq_percentile_workspace_bytes.restype = sz
+    L.mq_percentile.restype = ctypes.c_int
+    L.mq_percentile.argtypes = [vp, i32, i64, ctypes.c_double, vp, vp, vp, sz, vp]
+    L.mq_error_workspace_bytes.restype = sz
+    L.mq_error_workspace_bytes.argtypes = [i64, i64, i32]
+    L.mq_error_stats.restype = ctypes.c_int
+    L.mq_error_stats.argtypes = [vp, vp, i32, i64, i64, i64, vp, i32, vp, vp, vp, vp, sz, vp]
+    L.mq_bucketize_f16.restype = ctypes.c_int
+    L.mq_bucketize_f16.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_double), i32, vp, vp]
+    L.mq_compare_formats_f16.restype = ctypes.c_int
+    L.mq_compare_formats_f16.argtypes = [vp, ctypes.POINTER(vp), i32, i64, ctypes.c_uint16, vp, vp, vp]
+    L._err_bound = True
+    return L
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+@torch.no_grad()
+def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False):
+    """np.percentile(x, pct) (method 'linear') of a non-negative float32 / float64 device tensor, exact:
+    two-pass (float32) or four-pass (float64) radix select on the bit patterns.  Returns a 0-d device
+    tensor of x's dtype (and the two interpolated order statistics when return_pair)."""
+    x = require_device(x)
+    if x.dtype not in (torch.float32, torch.float64):
+        raise ValueError("percentile() takes float32 or float64")
+    x = x.contiguous().reshape(-1)
+    if x.numel() == 0:
+        raise IndexError("percentile of an empty array")
+    L = _bind()
+    out = torch.empty((), dtype=x.dtype, device=x.device)
+    pair = torch.empty(2, dtype=x.dtype, device=x.device) if return_pair else None
+    with torch.cuda.device(x.device):
+        ws, stream = workspace(x.device, L.mq_percentile_workspace_bytes())
+        st = L.mq_percentile(x.data_ptr(), _DT[x.dtype], x.numel(), float(pct), out.data_ptr(), _ptr(pair),
+                             ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return (out, pair) if return_pair else out
+
+
+@torch.no_grad()
+def error_stats(a: torch.Tensor, b: torch.Tensor, seg_len: Optional[int] = None, abs_err=None,
+                cols: bool = False, totals: bool = True):
+    """One pass over (a, b): dict with 'totals' ([sum err^2, sum |err|], float64), 'seg_sse' (row-form sums
+    over runs of seg_len), 'col_sse' (per-column sums), 'abs_err' (float32, or float16 arithmetic for
+    float16 inputs)."""
+    a, b = require_device(a), require_device(b).to(a.device)
+    if a.shape != b.shape:
+        raise ValueError("shape mismatch")
+    if a.dtype != b.dtype or a.dtype not in (torch.float16, torch.float32):
+        a, b = a.float(), b.float()  # the scripts widen everything to float32 (proto_to_array :35-38)
+    a, b = a.contiguous(), b.contiguous()
+    ncols = a.shape[-1] if a.dim() else 1
+    nrows = a.numel() // ncols if ncols else 0
+    dev = a.device
+    res = {}
+    if totals:
+        res["totals"] = torch.zeros(2, dtype=torch.float64, device=dev)
+    if seg_len:
+        if a.numel() % seg_len:
+            raise RuntimeError("group size mismatch")
+        res["seg_sse"] = torch.empty(a.numel() // seg_len, dtype=torch.float64, device=dev)
+    if cols:
+        res["col_sse"] = torch.empty(ncols, dtype=torch.float64, device=dev)
+    if abs_err is not None:
+        res["abs_err"] = torch.empty(a.shape, dtype=abs_err, device=dev)
+    if a.numel() == 0:
+        return res
+    L = _bind()
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L.mq_error_workspace_bytes(nrows, ncols, int(cols)))
+        st = L.mq_error_stats(a.data_ptr(), b.data_ptr(), _DT[a.dtype], nrows, ncols, int(seg_len or 0),
+                              _ptr(res.get("abs_err")), _lib.F16 if abs_err == torch.float16 else _lib.F32,
+                              _ptr(res.get("seg_sse")), _ptr(res.get("col_sse")), _ptr(res.get("totals")),
+                              ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return res
+
+
+def compute_mse(a, b) -> float:
+    """float(np.mean((a32 - b32)**2)) -- quant_error_multi_weight.py:55-58, quant_error_single_weight.py:46-48."""
+    st = error_stats(a, b)
+    n = a.numel()
+    return float(st["totals"][0].item() / n) if n else float("nan")
+
+
+def compute_errors(a, b, grouping: str, gs: Optional[int], form: str = "multi", keep_per_vec: bool = False):
+    """mse_tensor, and for 2-D inputs the per-vector MSE list's mean (mse_rep) and P99 (mse_p99).
+
+    form="multi":  vectors are COLUMNS (per-channel) or column blocks of gs columns (per-group)
+                   -- quant_error_multi_weight.py:61-87
+    form="single": vectors are ROWS (per-channel) or (row, group) runs in row-major order (per-group)
+                   -- quant_error_single_weight.py:50-79 (without its plt.hist side effect)
+    """
+    a = require_device(a)
+    b = require_device(b)
+    K, C = (a.shape if a.dim() == 2 else (0, 0))
+    per_vec = None
+    if a.dim() == 2 and grouping in ("per-channel", "per-group"):
+        if grouping == "per-group":
+            assert gs and C % gs == 0, "group size mismatch"
+        if form == "multi":
+            st = error_stats(a, b, cols=True)
+            col = st["col_sse"]
+            per_vec = col / K if grouping == "per-channel" else col.reshape(C // gs, gs).sum(dim=1) / (K * gs)
+        else:
+            L = C if grouping == "per-channel" else gs
+            st = error_stats(a, b, seg_len=L)
+            per_vec = st["seg_sse"] / L
+    else:
+        st = error_stats(a, b)
+    result = {"mse_tensor": float(st["totals"][0].item() / a.numel())}
+    if per_vec is not None:
+        result["mse_rep"] = float(per_vec.mean().item())
+        result["mse_p99"] = float(percentile(per_vec, 99).item())
+        if keep_per_vec or form == "single":
+            result["per_vec"] = per_vec
+    return result
+
+
+class QuantizationErrorAnalyzer:
+    """The statistics half of elwise_error/onnx_error_cli.py:73-127 on two tensors (the ONNX loading and
+    the matplotlib plots stay on the CPU side): float32 element-wise error, its absolute value, P99 and
+    sum, and MSE / absolute-error sum of an index range."""
+
+    def __init__(self, w_fp16: torch.Tensor, w_quant: torch.Tensor, analysis_range: Optional[tuple] = None):
+        self.w_fp16 = require_device(w_fp16).float().reshape(-1)   # _load_weight: .astype(np.float32) (:110)
+        self.w_quant = require_device(w_quant).float().reshape(-1)
+        st = error_stats(self.w_fp16, self.w_quant, abs_err=torch.float32)
+        self.abs_elementwise_error = st["abs_err"]
+        self._totals = st["totals"]
+        self.analysis_range = analysis_range
+        self._sliced = None
+        if analysis_range:
+            start, end = analysis_range
+            end = min(end, self.w_fp16.numel())
+            self._sliced = error_stats(self.w_fp16[start:end], self.w_quant[start:end])
+            self._sliced_n = end - start
+
+    @property
+    def elementwise_error(self):
+        return self.w_fp16 - self.w_quant
+
+    def get_p99_error(self):
+        """np.percentile(abs_err, 99) (:113-114): float32, bit-exact."""
+        return percentile(self.abs_elementwise_error, 99)
+
+    def get_error_sum(self) -> float:
+        """np.sum(abs_err) (:116-117); accumulated in float64 here."""
+        return float(self._totals[1].item())
+
+    def get_sliced_mse(self) -> float:
+        return float(self._sliced["totals"][0].item() / self._sliced_n) if self._sliced else 0.0
+
+    def get_sliced_abs_error_sum(self) -> float:
+        return float(self._sliced["totals"][1].item()) if self._sliced else 0.0
+
+
+@torch.no_grad()
+def bucketize(w_fp16: torch.Tensor, w_q: torch.Tensor, step: float = 0.0001, max_value: float = 0.0007):
+    """single_weight_quant_error.py:39-52: float16 |w - w_q|, bins arange(step, max+step, step),
+    idx = min(np.digitize(abs, bins, right=True), len(bins)-1), value = idx * step.
+    Returns (abs_err float16, idx uint8, values float64 on the host for the bucket levels)."""
+    a = require_device(w_fp16).half().contiguous().reshape(-1)
+    b = require_device(w_q).half().contiguous().reshape(-1).to(a.device)
+    abs_err = error_stats(a, b, abs_err=torch.float16, totals=False)["abs_err"]
+    bins = np.arange(step, max_value + step, step)
+    values = np.arange(len(bins)) * step
+    if len(bins) > 64:
+        raise ValueError("at most 64 buckets")
+    idx = torch.empty(a.numel(), dtype=torch.uint8, device=a.device)
+    L = _bind()
+    with torch.cuda.device(a.device):
+        st = L.mq_bucketize_f16(abs_err.data_ptr(), a.numel(), bins.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                len(bins), idx.data_ptr(), torch.cuda.current_stream(a.device).cuda_stream)
+    _lib.check(st)
+    return abs_err, idx, values
+
+
+@torch.no_grad()
+def compare_formats(w_fp16: torch.Tensor, w_qs: Sequence[torch.Tensor], threshold: float = 0.02):
+    """compare.py:99-125: per-format float16 |w - w_q|, element-wise minimum, outlier mask (min > threshold)
+    and per-format "is best" masks.  Returns dict(min_err float16, mask_out bool, best list of bool)."""
+    if not 1 <= len(w_qs) <= 7:
+        raise ValueError("1..7 formats")
+    w = require_device(w_fp16).half().contiguous().reshape(-1)
+    qs = [require_device(q).half().contiguous().reshape(-1).to(w.device) for q in w_qs]
+    n = w.numel()
+    flags = torch.empty(n, dtype=torch.uint8, device=w.device)
+    min_err = torch.empty(n, dtype=torch.float16, device=w.device)
+    arr = (ctypes.c_void_p * len(qs))(*[q.data_ptr() for q in qs])
+    thr_bits = int(np.float16(threshold).view(np.uint16))
+    L = _bind()
+    with torch.cuda.device(w.device):
+        st = L.mq_compare_formats_f16(w.data_ptr(), arr, len(qs), n, thr_bits, flags.data_ptr(), min_err.data_ptr(),
+                                      torch.cuda.current_stream(w.device).cuda_stream)
+    _lib.check(st)
+    return {"min_err": min_err, "mask_out": (flags & 0x80) != 0,
+            "best": [(flags & (1 << i)) != 0 for i in range(len(qs))], "flags": flags}
+
+
+@torch.no_grad()
+def to_ranges(mask: torch.Tensor) -> List[tuple]:
+    """compare.py:130-143 for a boolean mask: [(start, length), ...] of its runs of True, computed with
+    device-side differences instead of a Python loop over indices."""
+    m = mask.reshape(-1).to(torch.int8)
+    if m.numel() == 0:
+        return []
+    d = torch.diff(m, prepend=m.new_zeros(1), append=m.new_zeros(1))
+    starts = torch.nonzero(d == 1).reshape(-1)
+    ends = torch.nonzero(d == -1).reshape(-1)
+    return list(zip(starts.tolist(), (ends - starts).tolist()))

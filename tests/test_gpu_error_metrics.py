@@ -1,0 +1,151 @@
+"""GPU: percentile (radix select), error statistics, bucketing and format comparison against numpy /
+the numpy restatement of the reference's analysis scripts and the stored known answers.
+Bit-exact: percentiles of a given array, element-wise errors, bucket indices, masks.
+Within 1e-6 relative (float64 vs numpy's float32 pairwise sums): MSE values and sums."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def em():
+    from quantization_amd import _lib, error_metrics
+    _lib.lib()
+    assert torch.cuda.is_available()
+    return error_metrics
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _arrays(dtype):
+    rng = np.random.default_rng(5)
+    yield "one", np.array([0.25], dtype)
+    yield "two", np.array([3.0, 1.0], dtype)
+    yield "seven", np.abs(rng.standard_normal(7)).astype(dtype)
+    yield "1000", np.abs(rng.standard_normal(1000)).astype(dtype)
+    yield "100003", (np.abs(rng.standard_normal(100003)) * 1e-4).astype(dtype)
+    yield "all_equal", np.full(300001, 0.0123, dtype)
+    yield "mostly_zero", np.where(rng.random(400000) < 0.995, 0, rng.random(400000)).astype(dtype)
+    yield "few_levels", (rng.integers(0, 5, 1 << 20) * np.float64(2.0 ** -12)).astype(dtype)
+    yield "wide_range", np.exp(rng.standard_normal(1 << 21) * 8).astype(dtype)
+    yield "5M", np.abs(rng.standard_normal(5_000_001) * 0.003).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_percentile_matches_numpy_bits(em, dtype):
+    for name, arr in _arrays(dtype):
+        x = torch.from_numpy(arr).cuda()
+        for pct in (99, 50, 0, 100, 99.9, 12.5):
+            want = np.percentile(arr, pct)
+            got = em.percentile(x, pct).cpu().numpy()
+            assert got.dtype == arr.dtype
+            assert got.tobytes() == np.asarray(want, dtype).tobytes(), (name, pct, got, want)
+
+
+def test_percentile_large_index_rounding(em):
+    """n - 1 beyond 2^24: numpy's float32 virtual index is a rounded integer (gamma == 0)."""
+    rng = np.random.default_rng(9)
+    arr = np.abs(rng.standard_normal(4096 * 4096 + 3)).astype(np.float32)
+    got = em.percentile(torch.from_numpy(arr).cuda(), 99).cpu().numpy()
+    assert got.tobytes() == np.float32(np.percentile(arr, 99)).tobytes()
+
+
+def _gold_inputs():
+    gold = gu.load_json("error_stats.json")
+    K, C = gold["K"], gold["C"]
+    rng = np.random.default_rng(gold["seed"])
+    inputs = {"normal": (rng.standard_normal((K, C)) * 0.02).astype(np.float16),
+              "student_t": (rng.standard_t(3, (K, C)) * 0.02).astype(np.float16)}
+    return gold, inputs
+
+
+def _quant_on_gpu(w16, fmt, gs):
+    import quantization_amd as qa
+    w = torch.from_numpy(w16).cuda()
+    qw = qa.quant_weight
+    if fmt == "int8":
+        return qw.quant_int(w, 8, gs)
+    if fmt == "int8_asym":
+        return qw.quant_int_asym(w, 8, gs)
+    return qw.quant_datatype(w, 8, fmt, gs)
+
+
+def test_known_answers(em, oracle):
+    gold, inputs = _gold_inputs()
+    for cname, w16 in inputs.items():
+        g = gold["cases"][cname]
+        assert _digest(w16) == g["input_sha256"]
+        w = torch.from_numpy(w16).cuda()
+        for key, e in g["formats"].items():
+            fmt, gk = key.split("/")
+            gs = None if gk == "none" else int(gk)
+            deq = _quant_on_gpu(w16, fmt, gs)
+            assert _digest(deq.view(torch.int16).cpu().numpy().view(np.uint16)) == e["deq_sha256"]
+            grouping = "per-channel" if gs is None else "per-group"
+            a32, b32 = w.float(), deq.float()
+            multi = em.compute_errors(a32, b32, grouping, gs, form="multi")
+            single = em.compute_errors(a32, b32, grouping, gs, form="single")
+            for got, want in ((multi["mse_tensor"], e["mse_tensor"]), (single["mse_tensor"], e["mse_tensor"]),
+                              (multi["mse_rep"], e["multi"]["mse_rep"]), (multi["mse_p99"], e["multi"]["mse_p99"]),
+                              (single["mse_rep"], e["single"]["mse_rep"]), (single["mse_p99"], e["single"]["mse_p99"])):
+                assert abs(got - want) <= 1e-6 * abs(want), (cname, key, got, want)
+            an = em.QuantizationErrorAnalyzer(w, deq, analysis_range=(1000, 200000))
+            assert _digest(an.abs_elementwise_error.cpu().numpy()) == e["abs_sha256"]
+            p99 = an.get_p99_error().cpu().numpy()
+            assert int(p99.view(np.uint32)) == e["abs_p99_f32_bits"], (cname, key)
+            want_sum = float(np.uint32(e["abs_sum_f32_bits"]).view(np.float32))
+            assert abs(an.get_error_sum() - want_sum) <= 1e-6 * want_sum
+            want_smse = float(np.uint32(e["sliced_mse_f32_bits"]).view(np.float32))
+            want_ssum = float(np.uint32(e["sliced_abs_sum_f32_bits"]).view(np.float32))
+            assert abs(an.get_sliced_mse() - want_smse) <= 1e-6 * want_smse
+            assert abs(an.get_sliced_abs_error_sum() - want_ssum) <= 1e-6 * want_ssum
+            abs16, idx, values = em.bucketize(w, deq)
+            assert _digest(abs16.view(torch.int16).cpu().numpy().view(np.uint16)) == e["abs_f16_sha256"]
+            assert _digest(idx.cpu().numpy().astype(np.int64)) == e["bucket_idx_sha256"]
+        # compare.py on the three 8-bit formats, per-channel
+        c = g["compare"]
+        qs = [_quant_on_gpu(w16, f, None) for f in c["formats"]]
+        r = em.compare_formats(w, qs, threshold=0.02)
+        assert _digest(r["min_err"].view(torch.int16).cpu().numpy().view(np.uint16)) == c["min_err_sha256"]
+        assert int(r["mask_out"].sum()) == c["thr_0.02"]["n_out"]
+        for i, b in enumerate(r["best"]):
+            assert int(b.sum()) == c["thr_0.02"]["n_best"][i]
+            assert _digest(np.packbits(b.cpu().numpy())) == c["thr_0.02"]["best_sha256"][i]
+        r2 = em.compare_formats(w, qs, threshold=1e-4)
+        assert int(r2["mask_out"].sum()) == c["thr_1e-4"]["n_out"]
+        assert _digest(np.packbits(r2["mask_out"].cpu().numpy())) == c["thr_1e-4"]["out_sha256"]
+        assert len(em.to_ranges(r2["mask_out"])) == c["thr_1e-4"]["n_ranges_out"]
+
+
+def test_error_stats_shapes_vs_numpy(em, oracle):
+    """Row / column forms on ragged shapes (vector path, short teams, scalar fallback) against the numpy
+    restatement evaluated with float64 accumulation."""
+    rng = np.random.default_rng(3)
+    for (K, C, gs) in [(33, 256, 32), (7, 1024, 1024), (5, 1536, 96), (64, 40, 8), (6, 100, 20), (3, 8192, 128)]:
+        a = (rng.standard_normal((K, C)) * 0.02).astype(np.float16)
+        b = (a.astype(np.float32) + rng.standard_normal((K, C)).astype(np.float32) * 1e-4).astype(np.float16)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        d = a.astype(np.float32) - b.astype(np.float32)
+        sq = (d * d).astype(np.float64)
+        for dtype in (torch.float16, torch.float32):
+            st = em.error_stats(ta.to(dtype), tb.to(dtype), seg_len=gs, cols=(C % 8 == 0), abs_err=torch.float32)
+            np.testing.assert_allclose(st["totals"].cpu().numpy(), [sq.sum(), np.abs(d).astype(np.float64).sum()], rtol=2e-7)
+            np.testing.assert_allclose(st["seg_sse"].cpu().numpy(), sq.reshape(-1, gs).sum(1), rtol=2e-7)
+            if C % 8 == 0:
+                np.testing.assert_allclose(st["col_sse"].cpu().numpy(), sq.sum(0), rtol=1e-12)
+            assert np.array_equal(st["abs_err"].cpu().numpy(), np.abs(d))
+        m = em.compute_errors(ta.float(), tb.float(), "per-group", gs, form="single")
+        want = oracle.compute_errors_single(a.astype(np.float32), b.astype(np.float32), "per-group", gs)
+        assert abs(m["mse_p99"] - want["mse_p99"]) <= 1e-6 * want["mse_p99"]
+        assert abs(m["mse_rep"] - want["mse_rep"]) <= 1e-6 * want["mse_rep"]
+    # to_ranges against the oracle's run-length helper
+    mask = torch.from_numpy(rng.random(5000) < 0.3).cuda()
+    assert em.to_ranges(mask) == oracle.to_ranges(np.where(mask.cpu().numpy())[0])
