@@ -101,6 +101,24 @@ size_t mq_percentile_workspace_bytes(void);
 int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
                   void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/*
+ * The steps mq_percentile is made of, for selecting jointly from several arrays (a model-wide P99 over all
+ * layers) or from arrays on several GPUs (merge the histogram area with an all-reduce SUM of uint32 between
+ * accumulate and scan; every rank then runs the same scan).  No counterpart in the reference, which holds
+ * one array in host memory.  Order: begin -> accumulate(level 0, each array) -> [merge] -> scan(0) ->
+ * for level = 1 .. (1 for float32, 3 for float64): clear_digits -> accumulate(level, each array) -> [merge]
+ * -> scan(level);  then finish.  Ranks come from mq_percentile_index on the TOTAL element count.
+ */
+void mq_select_layout(size_t* top_offset, size_t* top_count, size_t* digit_offset, size_t* digit_count);
+int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t* k0, int64_t* k1, double* gamma);
+int mq_select_begin(int64_t k0, int64_t k1, void* workspace, size_t workspace_bytes, void* hip_stream);
+int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
+                         size_t workspace_bytes, void* hip_stream);
+int mq_select_clear_digits(void* workspace, size_t workspace_bytes, void* hip_stream);
+int mq_select_scan(int32_t level, void* workspace, size_t workspace_bytes, void* hip_stream);
+int mq_select_finish(int32_t dtype, double gamma, void* out, void* out_pair, void* workspace,
+                     size_t workspace_bytes, void* hip_stream);
+
 /* Bytes of device workspace mq_error_stats needs (want_cols: column sums requested). */
 size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t want_cols);
 

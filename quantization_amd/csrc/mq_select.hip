@@ -203,60 +203,152 @@ __global__ void k_sel_finish(const SelWs* ws, T gamma, T* out, T* out_pair) {
 // ================================================================================================
 extern "C" size_t mq_percentile_workspace_bytes(void) { return sizeof(SelWs); }
 
-template <typename T>
-static int run_select(const T* x, int64_t n, int64_t k0, int64_t k1, T gamma, T* out, T* out_pair, SelWs* ws,
-                      hipStream_t st) {
-  MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<T>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
-  hipLaunchKernelGGL(k_sel_init, dim3(32), dim3(256), 0, st, ws, (uint64_t)k0, (uint64_t)k1);
-  constexpr int V = 16 / sizeof(T);
-  int64_t nb = (n / V + 1024 * 4 - 1) / (1024 * 4);
-  unsigned grid_top = (unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
-  hipLaunchKernelGGL((k_sel_hist_top<T>), dim3(grid_top), dim3(1024), SEL_TOP_BINS * 4, st, x, n, ws->top);
-  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, ws, 0);
-  const int levels = sizeof(T) == 4 ? 1 : 3;
-  int64_t nb2 = (n / V + 256 * 4 - 1) / (256 * 4);
-  unsigned grid_d = (unsigned)(nb2 < 1 ? 1 : (nb2 > 1024 ? 1024 : nb2));
-  for (int level = 1; level <= levels; ++level) {
-    hipLaunchKernelGGL(k_sel_clear_digits, dim3(128), dim3(256), 0, st, ws);
-    hipLaunchKernelGGL((k_sel_hist_digit<T>), dim3(grid_d), dim3(256), 0, st, x, n, ws, level);
-    hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, st, ws, level);
+// Byte offsets / element counts of the two histogram areas inside the workspace, for callers that merge
+// histograms across devices (all-reduce SUM of uint32) between the steps below.
+extern "C" void mq_select_layout(size_t* top_offset, size_t* top_count, size_t* digit_offset, size_t* digit_count) {
+  if (top_offset) *top_offset = offsetof(SelWs, top);
+  if (top_count) *top_count = SEL_TOP_BINS;
+  if (digit_offset) *digit_offset = offsetof(SelWs, digit);
+  if (digit_count) *digit_count = 2 * SEL_DIGIT_BINS;
+}
+
+// numpy 2.2's index arithmetic for method 'linear', in the array's dtype:
+//   q = pct / dtype(100);  vi = (n - 1) * q;  k0 = floor(vi), k1 = k0 + 1, gamma = vi - k0
+//   (vi >= n - 1: both ranks are the last element)
+extern "C" int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t* k0, int64_t* k1, double* gamma) {
+  if (n <= 0 || !(pct >= 0.0 && pct <= 100.0) || !k0 || !k1 || !gamma) return MQ_ERR_ARG;
+  if (dtype == MQ_F32) {
+    float q = (float)pct / 100.0f;
+    float vi = (float)(n - 1) * q;
+    float prev = __builtin_floorf(vi);
+    *gamma = (double)(vi - prev);
+    *k0 = (int64_t)prev;
+    if (vi >= (float)(n - 1)) *k0 = n - 1;
+  } else if (dtype == MQ_F64) {
+    double q = pct / 100.0;
+    double vi = (double)(n - 1) * q;
+    double prev = __builtin_floor(vi);
+    *gamma = vi - prev;
+    *k0 = (int64_t)prev;
+    if (vi >= (double)(n - 1)) *k0 = n - 1;
+  } else {
+    return MQ_ERR_ARG;
   }
-  hipLaunchKernelGGL((k_sel_finish<T>), dim3(1), dim3(1), 0, st, ws, gamma, out, out_pair);
+  if (*k0 > n - 1) *k0 = n - 1;
+  *k1 = *k0 + 1 > n - 1 ? n - 1 : *k0 + 1;
+  return MQ_OK;
+}
+
+static int check_ws(const void* x, int32_t dtype, int64_t n, void* workspace, size_t workspace_bytes) {
+  if (n < 0 || (n > 0 && !x)) return MQ_ERR_ARG;
+  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(workspace) % 16) return MQ_ERR_ALIGN;
+  return MQ_OK;
+}
+
+// Step 1: clear the level-0 histogram and set the two ranks (global ranks when arrays on several devices
+// or several arrays are selected from jointly).
+extern "C" int mq_select_begin(int64_t k0, int64_t k1, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (k0 < 0 || k1 < k0) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_sel_init, dim3(32), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<SelWs*>(workspace), (uint64_t)k0, (uint64_t)k1);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+// Step 2 (level 0) / step 4 (level >= 1): add one array's contribution to the current level's histogram.
+// May be called for several arrays before the scan.  Level >= 1 histograms must be cleared first
+// (mq_select_clear_digits).
+extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
+                                    size_t workspace_bytes, void* hip_stream) {
+  int rc = check_ws(x, dtype, n, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (level < 0 || level > 3) return MQ_ERR_ARG;
+  if (n == 0) return MQ_OK;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  SelWs* ws = static_cast<SelWs*>(workspace);
+  const int V = dtype == MQ_F32 ? 4 : 2;
+  if (level == 0) {
+    int64_t nb = (n / V + 1024 * 4 - 1) / (1024 * 4);
+    unsigned grid = (unsigned)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    if (dtype == MQ_F32) {
+      MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<float>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
+      hipLaunchKernelGGL((k_sel_hist_top<float>), dim3(grid), dim3(1024), SEL_TOP_BINS * 4, st,
+                         static_cast<const float*>(x), n, ws->top);
+    } else {
+      MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<double>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
+      hipLaunchKernelGGL((k_sel_hist_top<double>), dim3(grid), dim3(1024), SEL_TOP_BINS * 4, st,
+                         static_cast<const double*>(x), n, ws->top);
+    }
+  } else {
+    int64_t nb = (n / V + 256 * 4 - 1) / (256 * 4);
+    unsigned grid = (unsigned)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    if (dtype == MQ_F32)
+      hipLaunchKernelGGL((k_sel_hist_digit<float>), dim3(grid), dim3(256), 0, st, static_cast<const float*>(x), n, ws, level);
+    else
+      hipLaunchKernelGGL((k_sel_hist_digit<double>), dim3(grid), dim3(256), 0, st, static_cast<const double*>(x), n, ws, level);
+  }
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+extern "C" int mq_select_clear_digits(void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_sel_clear_digits, dim3(128), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<SelWs*>(workspace));
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+// Step 3 / 5: locate the ranks in the (merged) histogram of `level` and extend the prefixes.
+extern "C" int mq_select_scan(int32_t level, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (level < 0 || level > 3) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(hip_stream),
+                     static_cast<SelWs*>(workspace), (int)level);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+// Last step: the two order statistics and numpy's interpolation between them, in `dtype`.
+extern "C" int mq_select_finish(int32_t dtype, double gamma, void* out, void* out_pair, void* workspace,
+                                size_t workspace_bytes, void* hip_stream) {
+  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const SelWs* ws = static_cast<const SelWs*>(workspace);
+  if (dtype == MQ_F32)
+    hipLaunchKernelGGL((k_sel_finish<float>), dim3(1), dim3(1), 0, st, ws, (float)gamma, static_cast<float*>(out),
+                       static_cast<float*>(out_pair));
+  else
+    hipLaunchKernelGGL((k_sel_finish<double>), dim3(1), dim3(1), 0, st, ws, gamma, static_cast<double*>(out),
+                       static_cast<double*>(out_pair));
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 
 // np.percentile(x, pct) for a non-negative float32 / float64 array in device memory (the sign bit is
-// ignored, i.e. the percentile of |x| is returned).  The virtual index (n - 1) * (pct / 100), its floor
-// and the interpolation weight are computed in the array's dtype, as numpy 2.2 does.
+// ignored, i.e. the percentile of |x| is returned): the steps above on one array.
 extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
                              void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (!x || n <= 0 || !(pct >= 0.0 && pct <= 100.0) || (!out && !out_pair)) return MQ_ERR_ARG;
-  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
-  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
-  if (reinterpret_cast<uintptr_t>(x) % 16 || reinterpret_cast<uintptr_t>(workspace) % 16) return MQ_ERR_ALIGN;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  SelWs* ws = static_cast<SelWs*>(workspace);
+  if (!x || n <= 0 || (!out && !out_pair)) return MQ_ERR_ARG;
+  int rc = check_ws(x, dtype, n, workspace, workspace_bytes);
+  if (rc) return rc;
   int64_t k0, k1;
-  if (dtype == MQ_F32) {
-    float q = (float)pct / 100.0f;          // np.true_divide(q, float32(100))
-    float vi = (float)(n - 1) * q;           // (n - 1) * quantiles, float32
-    float prev = __builtin_floorf(vi);
-    float gamma = vi - prev;
-    k0 = (int64_t)prev; k1 = k0 + 1;
-    if (vi >= (float)(n - 1)) { k0 = k1 = n - 1; }
-    if (k1 > n - 1) k1 = n - 1;
-    return run_select<float>(static_cast<const float*>(x), n, k0, k1, gamma, static_cast<float*>(out),
-                             static_cast<float*>(out_pair), ws, st);
+  double gamma;
+  if ((rc = mq_percentile_index(dtype, n, pct, &k0, &k1, &gamma))) return rc;
+  if ((rc = mq_select_begin(k0, k1, workspace, workspace_bytes, hip_stream))) return rc;
+  if ((rc = mq_select_accumulate(x, dtype, n, 0, workspace, workspace_bytes, hip_stream))) return rc;
+  if ((rc = mq_select_scan(0, workspace, workspace_bytes, hip_stream))) return rc;
+  const int levels = dtype == MQ_F32 ? 1 : 3;
+  for (int level = 1; level <= levels; ++level) {
+    if ((rc = mq_select_clear_digits(workspace, workspace_bytes, hip_stream))) return rc;
+    if ((rc = mq_select_accumulate(x, dtype, n, level, workspace, workspace_bytes, hip_stream))) return rc;
+    if ((rc = mq_select_scan(level, workspace, workspace_bytes, hip_stream))) return rc;
   }
-  double q = pct / 100.0;
-  double vi = (double)(n - 1) * q;
-  double prev = __builtin_floor(vi);
-  double gamma = vi - prev;
-  k0 = (int64_t)prev; k1 = k0 + 1;
-  if (vi >= (double)(n - 1)) { k0 = k1 = n - 1; }
-  if (k1 > n - 1) k1 = n - 1;
-  return run_select<double>(static_cast<const double*>(x), n, k0, k1, gamma, static_cast<double*>(out),
-                            static_cast<double*>(out_pair), ws, st);
+  return mq_select_finish(dtype, gamma, out, out_pair, workspace, workspace_bytes, hip_stream);
 }

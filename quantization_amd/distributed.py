@@ -1,0 +1,129 @@
+"""Whole-model runs over the GPUs of one node: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI).  Linear layers are independent, so they are sharded by size and no weight ever crosses
+GPUs; RCCL carries only (1) the per-layer statistics records -- one small all-reduce per sweep -- and
+(2) the uint32 histograms of a percentile taken jointly over tensors on several GPUs.  The reference has
+no counterpart (single CPU process)."""
+import ctypes
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+def lpt_partition(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Greedy longest-processing-time assignment of items to `world` bins; returns per-rank index lists
+    (each in ascending order).  Deterministic: ties go to the lower rank."""
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    load = [0] * world
+    parts: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        parts[r].append(i)
+        load[r] += sizes[i]
+    return [sorted(p) for p in parts]
+
+
+def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tensor], n_total: int, width: int,
+                   device, group=None) -> torch.Tensor:
+    """Every rank contributes the rows it owns; all ranks get the full [n_total, width] float64 table.
+    One all-reduce(SUM) of a zero-filled table (tens of KiB: latency-bound)."""
+    import torch.distributed as dist
+    table = torch.zeros(n_total, width, dtype=torch.float64, device=device)
+    if len(local_idx):
+        table[torch.as_tensor(list(local_idx), device=device)] = local_records.to(torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
+def analyze_sharded(layers: Sequence, sizes: Sequence[int], analyze_fn: Callable, width: int, device, group=None):
+    """layers[i] is whatever analyze_fn needs to produce layer i's record (a float64[width] tensor on
+    `device`).  Returns (full table on every rank, indices this rank processed)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    mine = lpt_partition(sizes, world)[rank]
+    recs = [analyze_fn(layers[i]) for i in mine]
+    local = torch.stack(recs) if recs else None
+    return gather_records(mine, local, len(layers), width, device, group), mine
+
+
+# --------------------------------------------------------------------------------------------------
+# percentile over several tensors, possibly on several GPUs
+# --------------------------------------------------------------------------------------------------
+def _bind_select():
+    L = _lib.lib()
+    if getattr(L, "_sel_bound", False):
+        return L
+    vp, i64, i32, sz, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_double
+    L.mq_percentile_workspace_bytes.restype = sz
+    L.mq_select_layout.restype = None
+    L.mq_select_layout.argtypes = [ctypes.POINTER(sz)] * 4
+    L.mq_percentile_index.restype = ctypes.c_int
+    L.mq_percentile_index.argtypes = [i32, i64, dbl, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(dbl)]
+    L.mq_select_begin.restype = ctypes.c_int
+    L.mq_select_begin.argtypes = [i64, i64, vp, sz, vp]
+    L.mq_select_accumulate.restype = ctypes.c_int
+    L.mq_select_accumulate.argtypes = [vp, i32, i64, i32, vp, sz, vp]
+    L.mq_select_clear_digits.restype = ctypes.c_int
+    L.mq_select_clear_digits.argtypes = [vp, sz, vp]
+    L.mq_select_scan.restype = ctypes.c_int
+    L.mq_select_scan.argtypes = [i32, vp, sz, vp]
+    L.mq_select_finish.restype = ctypes.c_int
+    L.mq_select_finish.argtypes = [i32, dbl, vp, vp, vp, sz, vp]
+    L._sel_bound = True
+    return L
+
+
+@torch.no_grad()
+def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=None) -> torch.Tensor:
+    """np.percentile(np.concatenate(all tensors on all ranks), pct), exact, without moving the data:
+    every rank histograms its own tensors, the uint32 histograms are summed with one all-reduce per radix
+    level (128 KiB, then 512 KiB per further level), and every rank finishes the same selection.
+    All tensors: non-negative, same dtype (float32 or float64), on this rank's device.  A rank may pass
+    an empty list."""
+    import torch.distributed as dist
+    L = _bind_select()
+    dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dtype = tensors[0].dtype if tensors else None
+    if dist_on:
+        dts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(dts, str(dtype) if dtype is not None else None, group=group)
+        known = [d for d in dts if d is not None]
+        if not known or any(d != known[0] for d in known):
+            raise ValueError("joint_percentile: tensors must share one dtype and at least one rank must hold data")
+        dtype = {"torch.float32": torch.float32, "torch.float64": torch.float64}[known[0]]
+    if dtype not in (torch.float32, torch.float64):
+        raise ValueError("float32 or float64 tensors expected")
+    code = _lib.F32 if dtype == torch.float32 else 3
+    xs = [t.contiguous().reshape(-1) for t in tensors if t.numel()]
+    n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
+    if dist_on:
+        dist.all_reduce(n, group=group)
+    n = int(n.item())
+    k0, k1, gamma = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
+    _lib.check(L.mq_percentile_index(code, n, float(pct), ctypes.byref(k0), ctypes.byref(k1), ctypes.byref(gamma)))
+    nbytes = L.mq_percentile_workspace_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    offs = [ctypes.c_size_t() for _ in range(4)]
+    L.mq_select_layout(*[ctypes.byref(o) for o in offs])
+    top = ws[offs[0].value: offs[0].value + 4 * offs[1].value].view(torch.int32)
+    digit = ws[offs[2].value: offs[2].value + 4 * offs[3].value].view(torch.int32)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    wp, wn = ws.data_ptr(), ws.numel()
+    _lib.check(L.mq_select_begin(k0.value, k1.value, wp, wn, st))
+    levels = 1 if dtype == torch.float32 else 3
+    for level in range(levels + 1):
+        if level:
+            _lib.check(L.mq_select_clear_digits(wp, wn, st))
+        for x in xs:
+            _lib.check(L.mq_select_accumulate(x.data_ptr(), code, x.numel(), level, wp, wn, st))
+        if dist_on:
+            # counts stay far below 2^31 per bin per rank-sum for any tensor that fits a node
+            dist.all_reduce(top if level == 0 else digit, op=dist.ReduceOp.SUM, group=group)
+        _lib.check(L.mq_select_scan(level, wp, wn, st))
+    out = torch.empty((), dtype=dtype, device=dev)
+    _lib.check(L.mq_select_finish(code, gamma.value, out.data_ptr(), None, wp, wn, st))
+    return out

@@ -1,0 +1,98 @@
+"""Per-layer error reports: the per-tensor flow of MSE&P99/quant_error_multi_weight.py:119-164 and
+MSE&P99/plot.py:18-99 (reference paths under /root/reference), with the quantization itself fused in
+instead of read back from two ONNX files, and the same CSV schemas."""
+import csv
+import os
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .error_metrics import error_stats, percentile
+from .fused import LUT_FORMATS, quantize
+
+MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
+SINGLE_COLUMNS = ["datatype", "granularity", "bits", "num_channels", "groups_per_channel", "mse_tensor", "mse_rep",
+                  "mse_p99"]
+# columns of the per-layer record tensor produced on the device
+RECORD_FIELDS = ["numel", "sse", "sum_abs", "mse_rep", "mse_p99", "abs_p99"]
+
+
+def format_code(datatype: str) -> Tuple[int, Optional[str]]:
+    """'int8' / 'int4_asym' / 'fp8_e4m3' -> (mq_format, table name); the reference dispatches on the same
+    substrings (quant_weight.py:653-706)."""
+    if datatype.startswith("int"):
+        return (_lib.INT_ASYM if "asym" in datatype else _lib.INT_SYM), None
+    if datatype in LUT_FORMATS:
+        return _lib.LUT_FP, datatype
+    raise ValueError(f"Unsupported datatype {datatype}")
+
+
+def granularity(group_size) -> str:
+    return "per-group" if (group_size is not None and group_size > 0) else "per-channel"
+
+
+def quant_dir_name(bits: int, group_size) -> str:
+    """w_<bits>_gs_<gs|none>: the directory level export_and_quant.py:52-55 writes and parse_quant_config reads."""
+    return f"w_{bits}_gs_{group_size if (group_size is not None and group_size > 0) else 'none'}"
+
+
+def parse_quant_config(model_path: str):
+    """(grouping, datatype, bits, group_size) from .../<per-channel|per-group>/<dtype>/w_<b>_gs_<g>/model.onnx
+    -- quant_error_multi_weight.py:41-52."""
+    parts = model_path.split(os.sep)
+    for i, p in enumerate(parts):
+        if p in ("per-channel", "per-group"):
+            _, bits, _, gs = parts[i + 2].split("_")
+            return p, parts[i + 1], int(bits), (None if gs == "none" else int(gs))
+    return "baseline", os.path.basename(os.path.dirname(model_path)), None, None
+
+
+@torch.no_grad()
+def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: str = "single",
+                 abs_p99: bool = True, scratch: Optional[dict] = None) -> torch.Tensor:
+    """One weight -> float64[len(RECORD_FIELDS)] on the device, nothing synchronised.
+
+    form="single": the per-vector MSE list follows the quantization segments (rows / (row, group)), taken
+    from the fused pass for free.  form="multi": columns / column blocks of the stored tensor, which needs
+    the dequantized tensor and a second, column-wise pass."""
+    fmt, table = format_code(datatype)
+    K, C = w.shape
+    L = C if granularity(group_size) == "per-channel" else group_size
+    scratch = scratch if scratch is not None else {}
+    res = quantize(w, fmt, bits, group_size, table, deq=(form == "multi"), codes=False, scale=False,
+                   abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"), totals=True,
+                   out=scratch.get("res"))
+    scratch["res"] = res
+    rec = torch.zeros(len(RECORD_FIELDS), dtype=torch.float64, device=w.device)
+    rec[0] = w.numel()
+    rec[1:3] = res.totals
+    if form == "single":
+        per_vec = res.seg_sse / L
+    else:
+        col = error_stats(w.half() if w.dtype != torch.float16 else w, res.deq, cols=True, totals=False)["col_sse"]
+        per_vec = col / K if L == C else col.reshape(C // L, L).sum(dim=1) / (K * L)
+    rec[3] = per_vec.mean()
+    rec[4] = percentile(per_vec, 99)
+    if abs_p99:
+        rec[5] = percentile(res.abs_err, 99).double()
+    return rec
+
+
+def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size) -> List[Dict]:
+    """Device records -> the CSV rows of quant_error_multi_weight.py:142-151 (one host copy)."""
+    host = records.cpu().tolist()
+    rows = []
+    for name, r in zip(names, host):
+        rows.append({"initializer": name, "datatype": datatype, "granularity": granularity(group_size),
+                     "bits": bits or "", "mse_tensor": r[1] / r[0] if r[0] else float("nan"),
+                     "mse_rep": r[3], "mse_p99": r[4], "abs_sum": r[2], "abs_p99": r[5]})
+    return rows
+
+
+def write_csv(rows: List[Dict], path: str, columns=MULTI_COLUMNS) -> None:
+    """csv.DictWriter with the reference's column order; floats are written with repr() as csv does."""
+    with open(path, "w", newline="") as f:
+        wr = csv.DictWriter(f, fieldnames=columns, extrasaction="ignore")
+        wr.writeheader()
+        wr.writerows(rows)

@@ -1,0 +1,84 @@
+"""GPU: per-layer report records, the joint (multi-tensor / multi-rank) percentile, and a 2-rank run that
+merges percentile histograms across ranks (gloo carrying device tensors: the box has one GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _np_record(orc, w16, datatype, gs, form):
+    fmt = {"int8": orc.INT_SYM, "int8_asym": orc.INT_ASYM}.get(datatype, orc.LUT)
+    o = orc.quantize(w16, orc.F16, fmt, 8, gs, datatype=datatype if fmt == orc.LUT else None)
+    deq = o["deq"].view(np.float16)
+    a32, b32 = w16.astype(np.float32), deq.astype(np.float32)
+    grouping = "per-channel" if gs is None else "per-group"
+    ce = (orc.compute_errors_single if form == "single" else orc.compute_errors_multi)(a32, b32, grouping, gs)
+    el = orc.elementwise_f32(w16, deq)
+    return ce, el
+
+
+@pytest.mark.parametrize("form", ["single", "multi"])
+def test_layer_record_vs_oracle(oracle, form):
+    from quantization_amd import report
+    rng = np.random.default_rng(11)
+    w16 = (rng.standard_normal((96, 512)) * 0.02).astype(np.float16)
+    w = torch.from_numpy(w16).cuda()
+    for datatype in ("int8", "int8_asym", "fp8_e4m3", "fp8_e3m4"):
+        for gs in (None, 64):
+            rec = report.layer_record(w, datatype, 8, gs, form=form).cpu().numpy()
+            ce, el = _np_record(oracle, w16, datatype, gs, form)
+            assert rec[0] == w16.size
+            assert abs(rec[1] / rec[0] - ce["mse_tensor"]) <= 1e-6 * ce["mse_tensor"]
+            assert abs(rec[3] - ce["mse_rep"]) <= 1e-6 * ce["mse_rep"]
+            assert abs(rec[4] - ce["mse_p99"]) <= 1e-6 * ce["mse_p99"]
+            assert np.float32(rec[5]).tobytes() == np.float32(el["p99"]).tobytes()  # abs-error P99: bit-exact
+            assert abs(rec[2] - float(el["sum"])) <= 1e-6 * float(el["sum"])
+    rows = report.rows_from_records(["l0"], torch.from_numpy(rec)[None], "fp8_e3m4", 8, 64)
+    assert rows[0]["granularity"] == "per-group" and rows[0]["mse_p99"] == rec[4]
+
+
+def test_joint_percentile_single_process():
+    from quantization_amd.distributed import joint_percentile
+    rng = np.random.default_rng(2)
+    for dtype in (np.float32, np.float64):
+        parts = [np.abs(rng.standard_normal(n)).astype(dtype) * s for n, s in ((1000, 1), (77777, 1e-3), (5, 10), (300000, 0.1))]
+        want = np.percentile(np.concatenate(parts), 99)
+        got = joint_percentile([torch.from_numpy(p).cuda() for p in parts], 99).cpu().numpy()
+        assert got.tobytes() == np.asarray(want, dtype).tobytes()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from quantization_amd.distributed import joint_percentile
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(40)
+    parts = [np.abs(rng.standard_normal(n)).astype(np.float32) * s for n, s in ((50000, 1e-3), (120001, 2e-3), (333, 1.0))]
+    mine = [torch.from_numpy(p).cuda() for i, p in enumerate(parts) if i % world == rank]
+    got = joint_percentile(mine, 99).cpu().numpy()
+    want = np.float32(np.percentile(np.concatenate(parts), 99))
+    q.put((rank, got.tobytes() == want.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_histogram_merge_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
