@@ -84,6 +84,23 @@ size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cf
 int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
                 const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/* One tensor of a batch: its weight and where its results go. */
+typedef struct {
+  const void* w;
+  mq_quant_out out;
+} mq_quant_item;
+
+size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
+
+/*
+ * mq_quantize for `count` tensors of one shape, dtype and configuration in one launch per 32 tensors
+ * (the tensors' pointers travel in the kernel arguments; blockIdx.y selects the tensor).  The counterpart
+ * of the reference's per-Linear Python loop (quant_weight.py:660-704: every layer of a model has the same
+ * few shapes).  items is a HOST array; every item must request the same set of outputs.
+ */
+int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
+                      const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Bytes of device workspace mq_percentile needs (histograms + selection state). */
 size_t mq_percentile_workspace_bytes(void);
 
@@ -103,21 +120,19 @@ int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out
 
 /*
  * The steps mq_percentile is made of, for selecting jointly from several arrays (a model-wide P99 over all
- * layers) or from arrays on several GPUs (merge the histogram area with an all-reduce SUM of uint32 between
- * accumulate and scan; every rank then runs the same scan).  No counterpart in the reference, which holds
- * one array in host memory.  Order: begin -> accumulate(level 0, each array) -> [merge] -> scan(0) ->
- * for level = 1 .. (1 for float32, 3 for float64): clear_digits -> accumulate(level, each array) -> [merge]
- * -> scan(level);  then finish.  Ranks come from mq_percentile_index on the TOTAL element count.
+ * layers) or from arrays on several GPUs (merge that level's histogram with an all-reduce SUM of uint32
+ * between accumulate and scan; every rank then runs the same scan).  No counterpart in the reference, which
+ * holds one array in host memory.  Order: begin -> for level = 0 .. last (1 for float32, 3 for float64):
+ * accumulate(level, each array) -> [merge the area mq_select_layout(level) names] -> scan(level), the last
+ * scan with finish = 1.  The ranks k0 <= k1 and gamma come from mq_percentile_index on the TOTAL count.
  */
-void mq_select_layout(size_t* top_offset, size_t* top_count, size_t* digit_offset, size_t* digit_count);
+void mq_select_layout(int32_t level, size_t* offset, size_t* count);
 int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t* k0, int64_t* k1, double* gamma);
-int mq_select_begin(int64_t k0, int64_t k1, void* workspace, size_t workspace_bytes, void* hip_stream);
+int mq_select_begin(void* workspace, size_t workspace_bytes, void* hip_stream);
 int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
                          size_t workspace_bytes, void* hip_stream);
-int mq_select_clear_digits(void* workspace, size_t workspace_bytes, void* hip_stream);
-int mq_select_scan(int32_t level, void* workspace, size_t workspace_bytes, void* hip_stream);
-int mq_select_finish(int32_t dtype, double gamma, void* out, void* out_pair, void* workspace,
-                     size_t workspace_bytes, void* hip_stream);
+int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t finish, int32_t dtype, double gamma, void* out,
+                   void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* Bytes of device workspace mq_error_stats needs (want_cols: column sums requested). */
 size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t want_cols);

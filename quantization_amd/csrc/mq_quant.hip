@@ -55,6 +55,37 @@ struct QuantParams {
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
 };
 
+// Up to MQ_MAX_BATCH same-shaped tensors per launch (blockIdx.y picks the tensor); the per-tensor
+// pointers travel in the kernel arguments, so a batch needs no descriptor upload.
+#define MQ_MAX_BATCH 32
+struct BatchItem {
+  const void* w;
+  uint16_t* deq;
+  void* codes;
+  uint16_t* scale;
+  uint16_t* zp;
+  void* abs_err;
+  double* seg_sse;
+  double* totals;
+};
+struct QuantBatch {
+  QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
+  int64_t ws_stride;   // bytes between the tensors' workspace slices
+  BatchItem item[MQ_MAX_BATCH];
+};
+static const size_t kWsHeader = 256;  // reduction words at the start of a tensor's workspace slice
+
+__device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
+  QuantParams p = b.common;
+  const BatchItem& it = b.item[blockIdx.y];
+  p.w = it.w; p.deq = it.deq; p.codes = it.codes; p.scale = it.scale; p.zp = it.zp; p.abs_err = it.abs_err;
+  p.seg_sse = it.seg_sse;
+  char* ws = reinterpret_cast<char*>(const_cast<uint32_t*>(b.common.tred)) + (int64_t)blockIdx.y * b.ws_stride;
+  p.tred = reinterpret_cast<const uint32_t*>(ws);
+  p.partials = reinterpret_cast<double*>(ws + kWsHeader);
+  return p;
+}
+
 struct SegP {
   half_t s;    // scale
   half_t zp;   // zero-point (asym)
@@ -513,7 +544,8 @@ __device__ __forceinline__ void block_partials(const QuantParams& p, double sse,
 // vectors a lane holds belong to NV different segments.
 // ------------------------------------------------------------------------------------------------
 template <int FMT, int T, int NV>
-__global__ __launch_bounds__(256) void k_quant_team(QuantParams p) {
+__global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   double acc_sse = 0.0, acc_abs = 0.0;
   const int lane = threadIdx.x & 63;
@@ -671,7 +703,8 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
 }
 
 template <int FMT, int NV>
-__global__ __launch_bounds__(256) void k_quant_wave(QuantParams p) {
+__global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   double acc_sse = 0.0, acc_abs = 0.0;
   row_body<FMT, NV, false>(p, lds, acc_sse, acc_abs);
@@ -679,7 +712,8 @@ __global__ __launch_bounds__(256) void k_quant_wave(QuantParams p) {
 }
 
 template <int FMT, int NV, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_quant_block(QuantParams p) {
+__global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
   __shared__ double lds[96];
   double acc_sse = 0.0, acc_abs = 0.0;
   row_body<FMT, NV, true>(p, lds, acc_sse, acc_abs);
@@ -696,7 +730,9 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(QuantParams p) {
 __device__ __forceinline__ uint32_t h_key(uint32_t b) { return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u); }
 __device__ __forceinline__ uint32_t h_unkey(uint32_t k) { return (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu); }
 
-__global__ __launch_bounds__(256) void k_tensor_reduce(QuantParams p, uint32_t* tred) {
+__global__ __launch_bounds__(256) void k_tensor_reduce(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
+  uint32_t* tred = const_cast<uint32_t*>(p.tred);
   const int64_t nvec = p.n / 8;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   uint32_t amax = 0, kmax = 0, kmin = 0xffffu;
@@ -732,7 +768,8 @@ __global__ __launch_bounds__(256) void k_tensor_reduce(QuantParams p, uint32_t* 
 }
 
 template <int FMT, int NV>
-__global__ __launch_bounds__(256) void k_quant_tensor(QuantParams p) {
+__global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   double acc_sse = 0.0, acc_abs = 0.0;
   const int lane = threadIdx.x & 63;
@@ -796,7 +833,8 @@ __device__ __forceinline__ uint32_t load1_f16(const void* w, int dtype, int64_t 
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k_quant_generic(QuantParams p) {
+__global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
   __shared__ double lds[96];
   uint32_t* lds_u = reinterpret_cast<uint32_t*>(lds + 32);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -878,21 +916,24 @@ __global__ __launch_bounds__(256) void k_quant_generic(QuantParams p) {
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
-// Sum of the per-workgroup partials in a fixed order -> totals[0..1] (and seg_sse[0] for per-tensor).
-__global__ __launch_bounds__(256) void k_finalize_totals(const double* partials, int nblocks, double* totals,
-                                                         double* seg_sse0) {
+// Sum of a tensor's per-workgroup partials in a fixed order -> totals[0..1] (and seg_sse[0] for
+// per-tensor quantization).  One workgroup per tensor of the batch.
+__global__ __launch_bounds__(256) void k_finalize_totals(const QuantBatch b, int nblocks, int tensor_scope) {
   __shared__ double lds[32];
-  double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  const BatchItem& it = b.item[blockIdx.x];
+  const double* partials = reinterpret_cast<const double*>(
+      reinterpret_cast<const char*>(b.common.tred) + (int64_t)blockIdx.x * b.ws_stride + kWsHeader);
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += partials[2 * i]; c += partials[2 * i + 1]; }
   a = wave_sum(a);
-  b = wave_sum(b);
-  if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = a; lds[16 + (threadIdx.x >> 6)] = b; }
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = a; lds[16 + (threadIdx.x >> 6)] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double x = 0.0, y = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { x += lds[i]; y += lds[16 + i]; }
-    if (totals) { totals[0] = x; totals[1] = y; }
-    if (seg_sse0) seg_sse0[0] = x;
+    if (it.totals) { it.totals[0] = x; it.totals[1] = y; }
+    if (tensor_scope && it.seg_sse) it.seg_sse[0] = x;
   }
 }
 
@@ -949,7 +990,7 @@ static bool recip_ok_cached(float c) {
 }
 
 template <int FMT, int NV>
-static void launch_team(int team_log2, dim3 grid, hipStream_t st, const QuantParams& p) {
+static void launch_team(int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
   switch (team_log2) {
     case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV>), grid, dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((k_quant_team<FMT, 2, NV>), grid, dim3(256), 0, st, p); break;
@@ -962,7 +1003,7 @@ static void launch_team(int team_log2, dim3 grid, hipStream_t st, const QuantPar
 }
 
 template <int FMT>
-static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, hipStream_t st, const QuantParams& p) {
+static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
   if (scope == SC_SUBWAVE) {
     launch_team<FMT, 4>(team_log2, grid, st, p);
   } else if (scope == SC_TENSOR) {
@@ -987,7 +1028,6 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
   }
 }
 
-static const size_t kWsHeader = 256;  // reduction words, kept apart from the partials
 
 // Upper bound on the grid of the streaming kernels, in 256-thread workgroups.  4 per CU keeps every
 // wave looping over several tiles so that its prefetch overlaps its compute.  MQ_MAX_BLOCKS overrides
@@ -1001,27 +1041,21 @@ static int64_t grid_cap() {
   return cap;
 }
 
-extern "C" size_t mq_quantize_workspace_bytes(int64_t, int64_t, const mq_quant_cfg*) {
-  return kWsHeader + (size_t)MQ_MAX_GRID * 2 * sizeof(double);
+static size_t ws_slice_bytes() { return kWsHeader + (size_t)MQ_MAX_GRID * 2 * sizeof(double); }
+
+extern "C" size_t mq_quantize_workspace_bytes(int64_t, int64_t, const mq_quant_cfg*) { return ws_slice_bytes(); }
+extern "C" size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t, int64_t, const mq_quant_cfg*) {
+  return (size_t)(count < 1 ? 1 : (count > MQ_MAX_BATCH ? MQ_MAX_BATCH : count)) * ws_slice_bytes();
 }
 
-extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
-                           const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (!cfg || !out || rows < 0 || cols < 0) return MQ_ERR_ARG;
-  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
-  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && cfg->format != MQ_LUT_FP) return MQ_ERR_ARG;
-  if (out->abs_err && out->abs_err_dtype != MQ_F32 && out->abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
-  if (cfg->format != MQ_LUT_FP && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
-  if (cfg->f32_math && !(cfg->format == MQ_LUT_FP && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
-  const int64_t n = rows * cols;
-  if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
-  if (n == 0) return MQ_OK;
-  if (!w) return MQ_ERR_ARG;
-  if (!workspace || workspace_bytes < mq_quantize_workspace_bytes(rows, cols, cfg)) return MQ_ERR_WORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; }
 
-  QuantParams p = {};
-  p.w = w;
+// One launch (plus one finalize launch when totals are requested) for up to MQ_MAX_BATCH tensors.
+static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
+                           const mq_quant_cfg* cfg, void* workspace, hipStream_t st) {
+  const int64_t n = rows * cols;
+  QuantBatch b = {};
+  QuantParams& p = b.common;
   p.in_dtype = w_dtype;
   p.f32_math = cfg->f32_math;
   p.n = n;
@@ -1032,26 +1066,40 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
   else if (!lut_consts(cfg, cfg->f32_math != 0, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
   p.rqmax = 1.0f / p.qmax;
   p.qmax_recip_ok = recip_ok_cached(p.qmax);
-  p.deq = static_cast<uint16_t*>(out->deq);
-  p.codes = out->codes;
-  p.scale = static_cast<uint16_t*>(out->scale);
-  p.zp = static_cast<uint16_t*>(out->zero_point);
-  p.abs_err = out->abs_err;
-  p.abs_err_f16 = out->abs_err_dtype == MQ_F16;
-  p.seg_sse = out->seg_sse;
-  p.need_err = (out->abs_err || out->seg_sse || out->totals) ? 1 : 0;
-  uint32_t* tred = static_cast<uint32_t*>(workspace);
-  p.tred = tred;
-  p.partials = reinterpret_cast<double*>(static_cast<char*>(workspace) + kWsHeader);
-
-  // vector (16-byte) accesses need aligned bases and segments that are whole vectors
+  // which outputs exist is a property of the batch (taken from the first tensor, checked for the rest)
+  const mq_quant_out& o0 = items[0].out;
+  if (o0.abs_err && o0.abs_err_dtype != MQ_F32 && o0.abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
+  p.abs_err_f16 = o0.abs_err_dtype == MQ_F16;
+  p.need_err = (o0.abs_err || o0.seg_sse || o0.totals) ? 1 : 0;
+  p.tred = static_cast<const uint32_t*>(workspace);
+  b.ws_stride = (int64_t)ws_slice_bytes();
   const size_t esz = w_dtype == MQ_F32 ? 4 : 2;
-  auto al = [](const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
-  if (!al(w, esz) || !al(out->deq, 2) || !al(out->scale, 2) || !al(out->zero_point, 2) ||
-      !al(out->seg_sse, 8) || !al(out->totals, 8) || !al(workspace, 16) ||
-      !al(out->abs_err, out->abs_err_dtype == MQ_F16 ? 2 : 4) || (cfg->format == MQ_LUT_FP && !al(out->codes, 2)))
-    return MQ_ERR_ALIGN;
-  const bool vec_ok = (p.L % 8 == 0) && al(w, 16) && al(out->deq, 16) && al(out->codes, 16) && al(out->abs_err, 16);
+  bool vec_ok = p.L % 8 == 0;
+  for (int i = 0; i < count; ++i) {
+    const mq_quant_out& o = items[i].out;
+    if (!items[i].w) return MQ_ERR_ARG;
+    if (!o.deq != !o0.deq || !o.codes != !o0.codes || !o.scale != !o0.scale || !o.zero_point != !o0.zero_point ||
+        !o.abs_err != !o0.abs_err || !o.seg_sse != !o0.seg_sse || !o.totals != !o0.totals ||
+        (o.abs_err && o.abs_err_dtype != o0.abs_err_dtype))
+      return MQ_ERR_ARG;
+    if (!aligned(items[i].w, esz) || !aligned(o.deq, 2) || !aligned(o.scale, 2) || !aligned(o.zero_point, 2) ||
+        !aligned(o.seg_sse, 8) || !aligned(o.totals, 8) || !aligned(o.abs_err, p.abs_err_f16 ? 2 : 4) ||
+        (cfg->format == MQ_LUT_FP && !aligned(o.codes, 2)))
+      return MQ_ERR_ALIGN;
+    vec_ok = vec_ok && aligned(items[i].w, 16) && aligned(o.deq, 16) && aligned(o.codes, 16) && aligned(o.abs_err, 16);
+    BatchItem& it = b.item[i];
+    it.w = items[i].w;
+    it.deq = static_cast<uint16_t*>(o.deq);
+    it.codes = o.codes;
+    it.scale = static_cast<uint16_t*>(o.scale);
+    it.zp = static_cast<uint16_t*>(o.zero_point);
+    it.abs_err = o.abs_err;
+    it.seg_sse = o.seg_sse;
+    it.totals = o.totals;
+  }
+  // flags the kernels test through the (per-tensor) pointers: keep the common copy non-null where set
+  p.deq = b.item[0].deq; p.codes = b.item[0].codes; p.scale = b.item[0].scale; p.zp = b.item[0].zp;
+  p.abs_err = b.item[0].abs_err; p.seg_sse = b.item[0].seg_sse;
 
   int scope, nv = 4, threads = 256, team_log2 = 0;
   int64_t work_blocks;
@@ -1080,23 +1128,57 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
     work_blocks = p.nseg;
   }
   int64_t max_grid = scope == SC_BLOCK || scope == -1 ? (threads == 1024 ? MQ_MAX_GRID / 4 : MQ_MAX_GRID) : grid_cap();
-  dim3 grid((unsigned)(work_blocks < max_grid ? work_blocks : max_grid));
+  // a batch shares the chip: keep the total number of workgroups near the single-tensor cap
+  if (count > 1 && max_grid > 64) max_grid = max_grid / count < 64 ? 64 : max_grid / count;
+  dim3 grid((unsigned)(work_blocks < max_grid ? work_blocks : max_grid), (unsigned)count);
 
   if (scope == SC_TENSOR) {
-    MQ_HIP(hipMemsetAsync(tred, 0, 16, st));
+    for (int i = 0; i < count; ++i)
+      MQ_HIP(hipMemsetAsync(static_cast<char*>(workspace) + (size_t)i * ws_slice_bytes(), 0, 16, st));
     int64_t rb = (n / 8 + 255) / 256;
-    hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < MQ_MAX_GRID ? rb : MQ_MAX_GRID)), dim3(256), 0, st, p, tred);
+    int64_t cap = MQ_MAX_GRID / count < 64 ? 64 : MQ_MAX_GRID / count;
+    hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < cap ? rb : cap), (unsigned)count), dim3(256), 0, st, b);
   }
   switch (cfg->format) {
-    case MQ_INT_SYM: launch_fmt<MQ_INT_SYM>(scope, nv, threads, team_log2, grid, st, p); break;
-    case MQ_INT_ASYM: launch_fmt<MQ_INT_ASYM>(scope, nv, threads, team_log2, grid, st, p); break;
-    default: launch_fmt<MQ_LUT_FP>(scope, nv, threads, team_log2, grid, st, p); break;
+    case MQ_INT_SYM: launch_fmt<MQ_INT_SYM>(scope, nv, threads, team_log2, grid, st, b); break;
+    case MQ_INT_ASYM: launch_fmt<MQ_INT_ASYM>(scope, nv, threads, team_log2, grid, st, b); break;
+    default: launch_fmt<MQ_LUT_FP>(scope, nv, threads, team_log2, grid, st, b); break;
   }
   MQ_HIP(hipGetLastError());
-  if (out->totals || (scope == SC_TENSOR && out->seg_sse)) {
-    hipLaunchKernelGGL(k_finalize_totals, dim3(1), dim3(256), 0, st, p.partials, (int)grid.x, out->totals,
-                       scope == SC_TENSOR ? out->seg_sse : nullptr);
+  if (o0.totals || (scope == SC_TENSOR && o0.seg_sse)) {
+    hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, st, b, (int)grid.x,
+                       scope == SC_TENSOR ? 1 : 0);
     MQ_HIP(hipGetLastError());
   }
   return MQ_OK;
+}
+
+extern "C" int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows,
+                                 int64_t cols, const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes,
+                                 void* hip_stream) {
+  if (!cfg || count < 0 || rows < 0 || cols < 0 || (count > 0 && !items)) return MQ_ERR_ARG;
+  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && cfg->format != MQ_LUT_FP) return MQ_ERR_ARG;
+  if (cfg->format != MQ_LUT_FP && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math && !(cfg->format == MQ_LUT_FP && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
+  if (count == 0 || rows * cols == 0) return MQ_OK;
+  for (int32_t i = 0; i < count; ++i)
+    if (!items[i].w) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < mq_quantize_batch_workspace_bytes(count, rows, cols, cfg)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 16)) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  for (int32_t done = 0; done < count; done += MQ_MAX_BATCH) {
+    int32_t c = count - done < MQ_MAX_BATCH ? count - done : MQ_MAX_BATCH;
+    int rc = quantize_launch(items + done, c, w_dtype, rows, cols, cfg, workspace, st);
+    if (rc) return rc;
+  }
+  return MQ_OK;
+}
+
+extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
+                           const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!out) return MQ_ERR_ARG;
+  mq_quant_item item = {w, *out};
+  return mq_quantize_batch(&item, 1, w_dtype, rows, cols, cfg, workspace, workspace_bytes, hip_stream);
 }

@@ -33,7 +33,7 @@ struct SelWs {
   SelState st;
   uint32_t pad[48];
   uint32_t top[SEL_TOP_BINS];
-  uint32_t digit[2][SEL_DIGIT_BINS];
+  uint32_t digit[3][2][SEL_DIGIT_BINS];  // [level - 1][rank][bin]; cleared once per selection
 };
 
 __device__ __forceinline__ uint64_t key_of(float v) { return (uint64_t)(f_bits(v) & 0x7fffffffu) << 32; }
@@ -67,53 +67,102 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const T* x, int64_t n, ui
 }
 
 // ---- scan of a histogram: which bin holds each remaining rank --------------------------------------
-// One 1024-thread workgroup.  nbins is 32 768 (level 0) or 65 536; shift is the bit position of the digit.
-__global__ __launch_bounds__(1024) void k_sel_scan(SelWs* ws, int level) {
-  __shared__ uint64_t part[1024];
-  __shared__ SelState st, res;
-  const int nbins = level == 0 ? SEL_TOP_BINS : SEL_DIGIT_BINS;
-  const int shift = 48 - 16 * level;
-  const int per = nbins / 1024;
-  if (threadIdx.x == 0) { st = ws->st; res = ws->st; }
+// One 1024-thread workgroup.  Thread t owns PER consecutive bins and sums them with 16-byte loads; the
+// prefix over threads is a wave scan plus one LDS exchange; the one thread whose range holds a rank then
+// walks its bins again.  With finish_dtype != 0 the last level also performs numpy's interpolation
+// (lib/_function_base_impl.py::_lerp) in that dtype:
+//   r = a + (b - a) * t;  where t >= 0.5:  r = b - (b - a) * (1 - t)
+struct FinishArgs {
+  int32_t dtype;  // -1: no finish here; MQ_F32 / MQ_F64
+  double gamma;
+  void* out;
+  void* out_pair;
+};
+
+template <int PER>
+__device__ __forceinline__ void scan_hist(const uint32_t* h, int shift, const SelState& st, int r_lo, int r_hi,
+                                          SelState* res, uint64_t* wsum /*[16]*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u32x4* hv = reinterpret_cast<const u32x4*>(h) + threadIdx.x * (PER / 4);
+  uint64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < PER / 4; ++i) {
+    u32x4 v = hv[i];
+    sum += (uint64_t)v[0] + v[1] + v[2] + v[3];
+  }
+  uint64_t inc = sum;  // inclusive scan inside the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint64_t o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
   __syncthreads();
-  const bool shared_hist = level == 0 || st.same;
-  const int nsel = shared_hist ? 1 : 2;
-  for (int s = 0; s < nsel; ++s) {
-    const uint32_t* h = level == 0 ? ws->top : ws->digit[s];
-    uint64_t sum = 0;
-    for (int i = 0; i < per; ++i) sum += h[threadIdx.x * per + i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    // inclusive scan of the 1024 partial sums (Hillis-Steele)
-    for (int off = 1; off < 1024; off <<= 1) {
-      uint64_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-      __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
-    }
-    const uint64_t before = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    // ranks to place against this histogram: both while they share it, else rank s only
-    for (int r = 0; r < 2; ++r) {
-      if (!shared_hist && r != s) continue;
-      const uint64_t rk = st.rank[r];
-      if (rk >= before && rk < part[threadIdx.x]) {  // exactly one thread owns the rank
-        uint64_t acc = before;
-        for (int i = 0; i < per; ++i) {
-          uint32_t c = h[threadIdx.x * per + i];
-          if (rk < acc + c) {
-            res.prefix[r] = st.prefix[r] | ((uint64_t)(threadIdx.x * per + i) << shift);
-            res.rank[r] = rk - acc;
-            break;
-          }
-          acc += c;
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  uint64_t before = inc - sum;
+  for (int w = 0; w < wv; ++w) before += wsum[w];
+  for (int r = r_lo; r <= r_hi; ++r) {
+    const uint64_t rk = st.rank[r];
+    if (rk >= before && rk < before + sum) {  // exactly one thread owns the rank: it re-reads its bins
+      uint64_t acc = before;
+      int found = -1;
+      for (int i = 0; i < PER / 4 && found < 0; ++i) {
+        u32x4 v = hv[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (found < 0 && rk < acc + v[e]) { found = 4 * i + e; res->rank[r] = rk - acc; }
+          acc += v[e];
         }
       }
+      res->prefix[r] = st.prefix[r] | ((uint64_t)(threadIdx.x * PER + found) << shift);
     }
-    __syncthreads();
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k_sel_scan(SelWs* ws, int level, uint64_t k0, uint64_t k1, FinishArgs fin) {
+  __shared__ uint64_t wsum[16];
+  __shared__ SelState st, res;
+  if (threadIdx.x == 0) {
+    if (level == 0) {  // the ranks arrive with the first scan
+      SelState s0 = {};
+      s0.rank[0] = k0;
+      s0.rank[1] = k1;
+      s0.same = 1;
+      st = s0;
+    } else {
+      st = ws->st;
+    }
+    res = st;
+  }
+  __syncthreads();
+  const int shift = 48 - 16 * level;
+  if (level == 0) {
+    scan_hist<SEL_TOP_BINS / 1024>(ws->top, shift, st, 0, 1, &res, wsum);
+  } else if (st.same) {
+    scan_hist<SEL_DIGIT_BINS / 1024>(ws->digit[level - 1][0], shift, st, 0, 1, &res, wsum);
+  } else {
+    scan_hist<SEL_DIGIT_BINS / 1024>(ws->digit[level - 1][0], shift, st, 0, 0, &res, wsum);
+    scan_hist<SEL_DIGIT_BINS / 1024>(ws->digit[level - 1][1], shift, st, 1, 1, &res, wsum);
   }
   if (threadIdx.x == 0) {
     res.same = res.prefix[0] == res.prefix[1] ? 1 : 0;
     ws->st = res;
+    if (fin.dtype == MQ_F32) {
+      float a = f_from_bits((uint32_t)(res.prefix[0] >> 32)), b = f_from_bits((uint32_t)(res.prefix[1] >> 32));
+      float g = (float)fin.gamma, diff = b - a;
+      float r = a + diff * g;
+      if (g >= 0.5f) r = b - diff * (1.0f - g);
+      if (fin.out) *static_cast<float*>(fin.out) = r;
+      if (fin.out_pair) { static_cast<float*>(fin.out_pair)[0] = a; static_cast<float*>(fin.out_pair)[1] = b; }
+    } else if (fin.dtype == MQ_F64) {
+      double a = __builtin_bit_cast(double, res.prefix[0]), b = __builtin_bit_cast(double, res.prefix[1]);
+      double g = fin.gamma, diff = b - a;
+      double r = a + diff * g;
+      if (g >= 0.5) r = b - diff * (1.0 - g);
+      if (fin.out) *static_cast<double*>(fin.out) = r;
+      if (fin.out_pair) { static_cast<double*>(fin.out_pair)[0] = a; static_cast<double*>(fin.out_pair)[1] = b; }
+    }
   }
 }
 
@@ -143,7 +192,7 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const T* x, int64_t n, S
       if (old == 0u || old == d + 1u) { atomicAdd(&hcnt[s][h], 1u); return; }
       h = (h + 1) & (SEL_HASH - 1);
     }
-    atomicAdd(&ws->digit[s][d], 1u);
+    atomicAdd(&ws->digit[level - 1][s][d], 1u);
   };
   constexpr int V = 16 / sizeof(T);
   const int64_t nvec = n / V;
@@ -162,54 +211,23 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const T* x, int64_t n, S
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) {
     const int s = i / SEL_HASH, h = i % SEL_HASH;
-    if (hkey[s][h]) atomicAdd(&ws->digit[s][hkey[s][h] - 1u], hcnt[s][h]);
+    if (hkey[s][h]) atomicAdd(&ws->digit[level - 1][s][hkey[s][h] - 1u], hcnt[s][h]);
   }
-}
-
-__global__ void k_sel_clear_digits(SelWs* ws) {
-  uint32_t* d = &ws->digit[0][0];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * SEL_DIGIT_BINS; i += gridDim.x * blockDim.x) d[i] = 0;
-}
-__global__ void k_sel_init(SelWs* ws, uint64_t k0, uint64_t k1) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SEL_TOP_BINS; i += gridDim.x * blockDim.x) ws->top[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    SelState s = {};
-    s.rank[0] = k0;
-    s.rank[1] = k1;
-    s.same = 1;
-    ws->st = s;
-  }
-}
-
-// ---- interpolation: numpy's _lerp (lib/_function_base_impl.py) in the array's dtype ----------------
-//   r = a + (b - a) * t;  where t >= 0.5:  r = b - (b - a) * (1 - t)
-template <typename T>
-__global__ void k_sel_finish(const SelWs* ws, T gamma, T* out, T* out_pair) {
-  T a, b;
-  if constexpr (sizeof(T) == 4) {
-    a = f_from_bits((uint32_t)(ws->st.prefix[0] >> 32));
-    b = f_from_bits((uint32_t)(ws->st.prefix[1] >> 32));
-  } else {
-    a = __builtin_bit_cast(double, ws->st.prefix[0]);
-    b = __builtin_bit_cast(double, ws->st.prefix[1]);
-  }
-  T diff = b - a;
-  T r = a + diff * gamma;
-  if (gamma >= (T)0.5) r = b - diff * ((T)1 - gamma);
-  if (out) *out = r;
-  if (out_pair) { out_pair[0] = a; out_pair[1] = b; }
 }
 
 // ================================================================================================
 extern "C" size_t mq_percentile_workspace_bytes(void) { return sizeof(SelWs); }
 
-// Byte offsets / element counts of the two histogram areas inside the workspace, for callers that merge
-// histograms across devices (all-reduce SUM of uint32) between the steps below.
-extern "C" void mq_select_layout(size_t* top_offset, size_t* top_count, size_t* digit_offset, size_t* digit_count) {
-  if (top_offset) *top_offset = offsetof(SelWs, top);
-  if (top_count) *top_count = SEL_TOP_BINS;
-  if (digit_offset) *digit_offset = offsetof(SelWs, digit);
-  if (digit_count) *digit_count = 2 * SEL_DIGIT_BINS;
+// Byte offset / element count (uint32) of the histogram that `level` accumulates into, for callers that
+// merge histograms across devices (all-reduce SUM) between accumulate and scan.
+extern "C" void mq_select_layout(int32_t level, size_t* offset, size_t* count) {
+  if (level <= 0) {
+    if (offset) *offset = offsetof(SelWs, top);
+    if (count) *count = SEL_TOP_BINS;
+  } else {
+    if (offset) *offset = offsetof(SelWs, digit) + (size_t)(level - 1) * 2 * SEL_DIGIT_BINS * sizeof(uint32_t);
+    if (count) *count = 2 * SEL_DIGIT_BINS;
+  }
 }
 
 // numpy 2.2's index arithmetic for method 'linear', in the array's dtype:
@@ -247,20 +265,15 @@ static int check_ws(const void* x, int32_t dtype, int64_t n, void* workspace, si
   return MQ_OK;
 }
 
-// Step 1: clear the level-0 histogram and set the two ranks (global ranks when arrays on several devices
-// or several arrays are selected from jointly).
-extern "C" int mq_select_begin(int64_t k0, int64_t k1, void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (k0 < 0 || k1 < k0) return MQ_ERR_ARG;
+// Step 1: clear every histogram of the workspace (one fill).
+extern "C" int mq_select_begin(void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
-  hipLaunchKernelGGL(k_sel_init, dim3(32), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                     static_cast<SelWs*>(workspace), (uint64_t)k0, (uint64_t)k1);
-  MQ_HIP(hipGetLastError());
+  MQ_HIP(hipMemsetAsync(workspace, 0, sizeof(SelWs), static_cast<hipStream_t>(hip_stream)));
   return MQ_OK;
 }
 
-// Step 2 (level 0) / step 4 (level >= 1): add one array's contribution to the current level's histogram.
-// May be called for several arrays before the scan.  Level >= 1 histograms must be cleared first
-// (mq_select_clear_digits).
+// Step 2 (level 0) / step 4 (level >= 1): add one array's contribution to that level's histogram.
+// May be called for several arrays before the scan.
 extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
                                     size_t workspace_bytes, void* hip_stream) {
   int rc = check_ws(x, dtype, n, workspace, workspace_bytes);
@@ -296,43 +309,25 @@ extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int
   return MQ_OK;
 }
 
-extern "C" int mq_select_clear_digits(void* workspace, size_t workspace_bytes, void* hip_stream) {
+// Step 3 / 5: locate the ranks in the (merged) histogram of `level` and extend the prefixes.  The ranks
+// k0 <= k1 are read at level 0.  With finish != 0 (pass it at the last level: 1 for float32, 3 for
+// float64) the two order statistics and numpy's interpolation between them are written, in `dtype`, to
+// out (one value) and out_pair (two values); either may be NULL.
+extern "C" int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t finish, int32_t dtype, double gamma,
+                              void* out, void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (level < 0 || level > 3 || (level == 0 && (k0 < 0 || k1 < k0))) return MQ_ERR_ARG;
+  if (finish && dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
-  hipLaunchKernelGGL(k_sel_clear_digits, dim3(128), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
-                     static_cast<SelWs*>(workspace));
-  MQ_HIP(hipGetLastError());
-  return MQ_OK;
-}
-
-// Step 3 / 5: locate the ranks in the (merged) histogram of `level` and extend the prefixes.
-extern "C" int mq_select_scan(int32_t level, void* workspace, size_t workspace_bytes, void* hip_stream) {
-  if (level < 0 || level > 3) return MQ_ERR_ARG;
-  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  FinishArgs fin = {finish ? dtype : -1, gamma, out, out_pair};
   hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(hip_stream),
-                     static_cast<SelWs*>(workspace), (int)level);
-  MQ_HIP(hipGetLastError());
-  return MQ_OK;
-}
-
-// Last step: the two order statistics and numpy's interpolation between them, in `dtype`.
-extern "C" int mq_select_finish(int32_t dtype, double gamma, void* out, void* out_pair, void* workspace,
-                                size_t workspace_bytes, void* hip_stream) {
-  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
-  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const SelWs* ws = static_cast<const SelWs*>(workspace);
-  if (dtype == MQ_F32)
-    hipLaunchKernelGGL((k_sel_finish<float>), dim3(1), dim3(1), 0, st, ws, (float)gamma, static_cast<float*>(out),
-                       static_cast<float*>(out_pair));
-  else
-    hipLaunchKernelGGL((k_sel_finish<double>), dim3(1), dim3(1), 0, st, ws, gamma, static_cast<double*>(out),
-                       static_cast<double*>(out_pair));
+                     static_cast<SelWs*>(workspace), (int)level, (uint64_t)k0, (uint64_t)k1, fin);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 
 // np.percentile(x, pct) for a non-negative float32 / float64 array in device memory (the sign bit is
-// ignored, i.e. the percentile of |x| is returned): the steps above on one array.
+// ignored, i.e. the percentile of |x| is returned): the steps above on one array -- 5 launches for
+// float32 (fill, histogram, scan, matched-digit histogram, scan + interpolation), 9 for float64.
 extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
                              void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (!x || n <= 0 || (!out && !out_pair)) return MQ_ERR_ARG;
@@ -341,14 +336,13 @@ extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct
   int64_t k0, k1;
   double gamma;
   if ((rc = mq_percentile_index(dtype, n, pct, &k0, &k1, &gamma))) return rc;
-  if ((rc = mq_select_begin(k0, k1, workspace, workspace_bytes, hip_stream))) return rc;
-  if ((rc = mq_select_accumulate(x, dtype, n, 0, workspace, workspace_bytes, hip_stream))) return rc;
-  if ((rc = mq_select_scan(0, workspace, workspace_bytes, hip_stream))) return rc;
+  if ((rc = mq_select_begin(workspace, workspace_bytes, hip_stream))) return rc;
   const int levels = dtype == MQ_F32 ? 1 : 3;
-  for (int level = 1; level <= levels; ++level) {
-    if ((rc = mq_select_clear_digits(workspace, workspace_bytes, hip_stream))) return rc;
+  for (int level = 0; level <= levels; ++level) {
     if ((rc = mq_select_accumulate(x, dtype, n, level, workspace, workspace_bytes, hip_stream))) return rc;
-    if ((rc = mq_select_scan(level, workspace, workspace_bytes, hip_stream))) return rc;
+    if ((rc = mq_select_scan(level, k0, k1, level == levels, dtype, gamma, out, out_pair, workspace, workspace_bytes,
+                             hip_stream)))
+      return rc;
   }
-  return mq_select_finish(dtype, gamma, out, out_pair, workspace, workspace_bytes, hip_stream);
+  return MQ_OK;
 }

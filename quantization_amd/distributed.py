@@ -59,19 +59,15 @@ def _bind_select():
     vp, i64, i32, sz, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_size_t, ctypes.c_double
     L.mq_percentile_workspace_bytes.restype = sz
     L.mq_select_layout.restype = None
-    L.mq_select_layout.argtypes = [ctypes.POINTER(sz)] * 4
+    L.mq_select_layout.argtypes = [i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     L.mq_percentile_index.restype = ctypes.c_int
     L.mq_percentile_index.argtypes = [i32, i64, dbl, ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(dbl)]
     L.mq_select_begin.restype = ctypes.c_int
-    L.mq_select_begin.argtypes = [i64, i64, vp, sz, vp]
+    L.mq_select_begin.argtypes = [vp, sz, vp]
     L.mq_select_accumulate.restype = ctypes.c_int
     L.mq_select_accumulate.argtypes = [vp, i32, i64, i32, vp, sz, vp]
-    L.mq_select_clear_digits.restype = ctypes.c_int
-    L.mq_select_clear_digits.argtypes = [vp, sz, vp]
     L.mq_select_scan.restype = ctypes.c_int
-    L.mq_select_scan.argtypes = [i32, vp, sz, vp]
-    L.mq_select_finish.restype = ctypes.c_int
-    L.mq_select_finish.argtypes = [i32, dbl, vp, vp, vp, sz, vp]
+    L.mq_select_scan.argtypes = [i32, i64, i64, i32, i32, dbl, vp, vp, vp, sz, vp]
     L._sel_bound = True
     return L
 
@@ -107,23 +103,20 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     _lib.check(L.mq_percentile_index(code, n, float(pct), ctypes.byref(k0), ctypes.byref(k1), ctypes.byref(gamma)))
     nbytes = L.mq_percentile_workspace_bytes()
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    offs = [ctypes.c_size_t() for _ in range(4)]
-    L.mq_select_layout(*[ctypes.byref(o) for o in offs])
-    top = ws[offs[0].value: offs[0].value + 4 * offs[1].value].view(torch.int32)
-    digit = ws[offs[2].value: offs[2].value + 4 * offs[3].value].view(torch.int32)
     st = torch.cuda.current_stream(dev).cuda_stream
     wp, wn = ws.data_ptr(), ws.numel()
-    _lib.check(L.mq_select_begin(k0.value, k1.value, wp, wn, st))
+    out = torch.empty((), dtype=dtype, device=dev)
+    _lib.check(L.mq_select_begin(wp, wn, st))
     levels = 1 if dtype == torch.float32 else 3
     for level in range(levels + 1):
-        if level:
-            _lib.check(L.mq_select_clear_digits(wp, wn, st))
         for x in xs:
             _lib.check(L.mq_select_accumulate(x.data_ptr(), code, x.numel(), level, wp, wn, st))
         if dist_on:
-            # counts stay far below 2^31 per bin per rank-sum for any tensor that fits a node
-            dist.all_reduce(top if level == 0 else digit, op=dist.ReduceOp.SUM, group=group)
-        _lib.check(L.mq_select_scan(level, wp, wn, st))
-    out = torch.empty((), dtype=dtype, device=dev)
-    _lib.check(L.mq_select_finish(code, gamma.value, out.data_ptr(), None, wp, wn, st))
+            off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+            L.mq_select_layout(level, ctypes.byref(off), ctypes.byref(cnt))
+            # (bin counts stay far below 2^31 for anything that fits a node)
+            hist = ws[off.value: off.value + 4 * cnt.value].view(torch.int32)
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        _lib.check(L.mq_select_scan(level, k0.value, k1.value, int(level == levels), code, gamma.value,
+                                    out.data_ptr(), None, wp, wn, st))
     return out
