@@ -119,6 +119,15 @@ int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out
                   void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /*
+ * mq_percentile for `count` arrays of n values each (one dtype): out[i] (and out_pair[2 i], [2 i + 1])
+ * receive array i's result.  One set of launches per 32 arrays (blockIdx.y = array), each array with its
+ * own slice of the workspace.  xs is a HOST array of device pointers, each 16-byte aligned.
+ */
+size_t mq_percentile_batch_workspace_bytes(int32_t count);
+int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct, void* out,
+                        void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
  * The steps mq_percentile is made of, for selecting jointly from several arrays (a model-wide P99 over all
  * layers) or from arrays on several GPUs (merge that level's histogram with an all-reduce SUM of uint32
  * between accumulate and scan; every rank then runs the same scan).  No counterpart in the reference, which

@@ -27,6 +27,10 @@ def _bind():
     L.mq_percentile_workspace_bytes.restype = sz
     L.mq_percentile.restype = ctypes.c_int
     L.mq_percentile.argtypes = [vp, i32, i64, ctypes.c_double, vp, vp, vp, sz, vp]
+    L.mq_percentile_batch_workspace_bytes.restype = sz
+    L.mq_percentile_batch_workspace_bytes.argtypes = [i32]
+    L.mq_percentile_batch.restype = ctypes.c_int
+    L.mq_percentile_batch.argtypes = [ctypes.POINTER(vp), i32, i32, i64, ctypes.c_double, vp, vp, vp, sz, vp]
     L.mq_error_workspace_bytes.restype = sz
     L.mq_error_workspace_bytes.argtypes = [i64, i64, i32]
     L.mq_error_stats.restype = ctypes.c_int
@@ -63,6 +67,30 @@ def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False):
                              ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return (out, pair) if return_pair else out
+
+
+@torch.no_grad()
+def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
+    """np.percentile(x[i], pct) for every row of a [B, n] float32 / float64 device tensor (rows must be
+    contiguous and 16-byte aligned: n * itemsize % 16 == 0, or B == 1); one set of launches for all rows."""
+    x = require_device(x)
+    if x.dtype not in (torch.float32, torch.float64) or x.dim() != 2:
+        raise ValueError("percentile_batch() takes a 2-D float32 or float64 tensor")
+    x = x.contiguous()
+    B, n = x.shape
+    if n == 0:
+        raise IndexError("percentile of an empty array")
+    if (n * x.element_size()) % 16 and B > 1:
+        return torch.stack([percentile(x[i], pct) for i in range(B)])
+    L = _bind()
+    out = torch.empty(B, dtype=x.dtype, device=x.device)
+    ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() + i * n * x.element_size() for i in range(B)])
+    with torch.cuda.device(x.device):
+        ws, stream = workspace(x.device, L.mq_percentile_batch_workspace_bytes(min(B, 32)))
+        st = L.mq_percentile_batch(ptrs, B, _DT[x.dtype], n, float(pct), out.data_ptr(), None, ws.data_ptr(),
+                                   ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return out
 
 
 @torch.no_grad()

@@ -123,3 +123,93 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
                             ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return res
+
+
+class _QuantItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("out", _lib.QuantOut)]
+
+
+@torch.no_grad()
+def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
+                   f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, totals=False,
+                   out: Optional[QuantResult] = None) -> QuantResult:
+    """quantize() for a stack of same-shaped weights w[B, rows, cols] (e.g. one projection of every layer):
+    one fused launch per 32 tensors.  Every field of the result has a leading batch dimension."""
+    if w.dim() != 3:
+        raise ValueError("quantize_batch() expects [B, rows, cols]")
+    if w.dtype not in _DTYPES:
+        raise ValueError(f"unsupported weight dtype {w.dtype}")
+    if not w.is_cuda:
+        raise RuntimeError("quantize_batch() expects a ROCm device tensor")
+    w = w.contiguous()
+    B, rows, cols = w.shape
+    cfg = make_cfg(fmt, bits, group_size, datatype, f32_math)
+    gs = cfg.group_size
+    n = rows * cols
+    L = n if gs == -1 else (cols if gs <= 0 else gs)
+    if gs > 0 and cols % gs:
+        raise RuntimeError(f"shape '[{rows}, {cols // gs}, {gs}]' is invalid for input of size {n}")
+    nseg = n // L if L else 0
+    dev = w.device
+    res = out if out is not None else QuantResult(rows, cols, nseg)
+    res.rows, res.cols, res.nseg = rows, cols, nseg
+
+    # Per-tensor slices of the small outputs are padded to a multiple of 8 entries so that every slice keeps
+    # the 16-byte alignment the kernels want; the result exposes unpadded views.  The padded buffers are kept
+    # on the result object so that passing it back as `out` reuses them.
+    bufs = getattr(res, "_bufs", None) or {}
+
+    def buf(name, want, shape, dtype):
+        if not want:
+            bufs.pop(name, None)
+            return None
+        cur = bufs.get(name)
+        if cur is None or cur.shape != torch.Size(shape) or cur.dtype != dtype or cur.device != dev:
+            cur = torch.empty(shape, dtype=dtype, device=dev)
+            bufs[name] = cur
+        return cur
+
+    nseg_pad = (nseg + 7) // 8 * 8
+    b_deq = buf("deq", deq, (B, rows, cols), torch.float16)
+    b_codes = buf("codes", codes, (B, rows, cols), torch.float16 if fmt == _lib.LUT_FP else torch.uint8)
+    b_scale = buf("scale", scale, (B, nseg_pad), torch.float16)
+    b_zp = buf("zero_point", scale and fmt == _lib.INT_ASYM, (B, nseg_pad), torch.float16)
+    b_abs = buf("abs_err", abs_err is not None, (B, rows, cols), abs_err or torch.float32)
+    b_sse = buf("seg_sse", seg_sse, (B, nseg_pad), torch.float64)
+    b_tot = buf("totals", totals, (B, 2), torch.float64)
+    res._bufs = bufs
+    res.deq, res.codes, res.abs_err, res.totals = b_deq, b_codes, b_abs, b_tot
+    res.scale = None if b_scale is None else b_scale[:, :nseg]
+    res.zero_point = None if b_zp is None else b_zp[:, :nseg]
+    res.seg_sse = None if b_sse is None else b_sse[:, :nseg]
+    if n == 0 or B == 0:
+        if res.totals is not None:
+            res.totals.zero_()
+        return res
+
+    def at(t, i):
+        return None if t is None else t.data_ptr() + i * t.stride(0) * t.element_size()
+
+    items = (_QuantItem * B)()
+    aed = _lib.F16 if abs_err == torch.float16 else _lib.F32
+    for i in range(B):
+        items[i].w = at(w, i)
+        items[i].out = _lib.QuantOut(deq=at(b_deq, i), codes=at(b_codes, i), scale=at(b_scale, i),
+                                     zero_point=at(b_zp, i), abs_err=at(b_abs, i), abs_err_dtype=aed,
+                                     seg_sse=at(b_sse, i), totals=at(b_tot, i))
+    L_ = _lib.lib()
+    if not getattr(L_, "_batch_bound", False):
+        L_.mq_quantize_batch_workspace_bytes.restype = ctypes.c_size_t
+        L_.mq_quantize_batch_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                                         ctypes.POINTER(_lib.QuantCfg)]
+        L_.mq_quantize_batch.restype = ctypes.c_int
+        L_.mq_quantize_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]
+        L_._batch_bound = True
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
+        st = L_.mq_quantize_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(), ws.numel(),
+                                  stream.cuda_stream)
+    _lib.check(st)
+    return res

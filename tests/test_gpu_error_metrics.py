@@ -149,3 +149,14 @@ def test_error_stats_shapes_vs_numpy(em, oracle):
     # to_ranges against the oracle's run-length helper
     mask = torch.from_numpy(rng.random(5000) < 0.3).cuda()
     assert em.to_ranges(mask) == oracle.to_ranges(np.where(mask.cpu().numpy())[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_percentile_batch(em, dtype):
+    rng = np.random.default_rng(21)
+    for B, n in ((1, 1000), (5, 4096), (16, 100000), (40, 2048)):
+        arr = (np.abs(rng.standard_normal((B, n))) * rng.random((B, 1))).astype(dtype)
+        arr[0, : n // 2] = 0
+        got = em.percentile_batch(torch.from_numpy(arr).cuda(), 99).cpu().numpy()
+        want = np.array([np.percentile(arr[i], 99) for i in range(B)], dtype)
+        assert got.tobytes() == want.tobytes(), (B, n)

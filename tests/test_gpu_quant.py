@@ -252,3 +252,23 @@ def test_quant_model_walker(qa):
                        qa.quant_weight.quant_int_asym(w0, 8, 64).view(torch.int16))
     y = model(torch.randn(2, 256, device="cuda", dtype=torch.float16))
     assert y.shape == (2, 64)
+
+
+def test_batched_launch_equals_single(qa):
+    """quantize_batch (one launch, blockIdx.y = tensor) against per-tensor quantize: identical bits."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize_batch
+    torch.manual_seed(3)
+    for (B, rows, cols, gs) in [(5, 64, 512, 64), (3, 16, 2048, None), (2, 8, 16384, None), (4, 32, 256, -1), (35, 8, 128, 32)]:
+        w = (torch.randn(B, rows, cols, device="cuda") * 0.02).half()
+        for fmt, dt in ((_lib.INT_SYM, None), (_lib.INT_ASYM, None), (_lib.LUT_FP, "fp8_e3m4")):
+            rb = quantize_batch(w, fmt, 8, gs, dt, abs_err=torch.float32, seg_sse=True, totals=True)
+            for i in range(B):
+                r1 = qa.quantize(w[i], fmt, 8, gs, dt, abs_err=torch.float32, seg_sse=True, totals=True)
+                assert torch.equal(rb.deq[i].view(torch.int16), r1.deq.view(torch.int16))
+                assert torch.equal(rb.codes[i].view(torch.uint8), r1.codes.view(torch.uint8))
+                assert torch.equal(rb.scale[i].view(torch.int16), r1.scale.view(torch.int16))
+                if r1.zero_point is not None:
+                    assert torch.equal(rb.zero_point[i].view(torch.int16), r1.zero_point.view(torch.int16))
+                assert torch.equal(rb.abs_err[i], r1.abs_err)
+                assert torch.equal(rb.seg_sse[i], r1.seg_sse) and torch.equal(rb.totals[i], r1.totals)
