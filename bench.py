@@ -12,7 +12,7 @@ group sizes 32 / 64 / 128, returning dequantized weights, codes, scales, zero-po
 element-wise absolute-error dump, plus per-group and per-tensor squared-error sums, the mean and exact
 P99 of the per-group MSE vector and the exact P99 of the absolute error.  A step is one
 pass over a batch of 16 distinct matrices (512 MiB of weights, 5.4 GB of outputs -- more than the
-256 MiB Infinity Cache, so inputs come from HBM) x 3 group sizes = 48 fused launches.
+256 MiB Infinity Cache, so inputs come from HBM) x 3 group sizes = 48 tensor passes in 3 batched launches.
 
 One JSON line is printed by rank 0.
 """
@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 
 import quantization_amd as qa  # noqa: E402
 from quantization_amd import _lib  # noqa: E402
-from quantization_amd.error_metrics import percentile  # noqa: E402
+from quantization_amd.error_metrics import percentile_batch, vector_mse_stats  # noqa: E402
+from quantization_amd.fused import quantize_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -61,22 +62,22 @@ def algorithmic_bytes_per_elem(in_bytes, fmt, gs, outputs):
 
 
 class Workload:
+    """Passes are grouped into batches of same-shaped tensors: one fused launch (per 32 tensors) quantizes a
+    whole batch, one set of select launches takes all its P99s."""
+
     def __init__(self, name, device, rank):
         self.name = name
         g = torch.Generator(device=device)
-        self.passes = []  # (weight tensor, fmt, datatype, gs, outputs dict)
+        self.batches = []  # (stacked weights [B, rows, cols], fmt, datatype, gs, outputs dict)
         self.results = {}
         if name == "c2":
             self.desc = ("16x 4096x4096 fp16 N(0,0.02^2), int8-asym g=32/64/128: deq + codes + scale + zp + "
                          "abs-err(f32) dump + per-group/tensor MSE + exact P99 of |err| and of the per-group MSE")
             outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True, totals=True)
-            self.weights = []
-            for i in range(16):
-                g.manual_seed(1000 * rank + i)
-                self.weights.append((torch.randn(4096, 4096, generator=g, device=device) * 0.02).half())
+            g.manual_seed(1000 * rank)
+            w = (torch.randn(16, 4096, 4096, generator=g, device=device) * 0.02).half()
             for gs in (32, 64, 128):
-                for i, w in enumerate(self.weights):
-                    self.passes.append((i, w, _lib.INT_ASYM, None, gs, outs))
+                self.batches.append((w, _lib.INT_ASYM, None, gs, outs))
         else:
             shapes = (model_shapes(TINYLLAMA, 22, (32000, 2048)) if name == "tinyllama"
                       else model_shapes(LLAMA8B, 32, (128256, 4096)))
@@ -84,32 +85,33 @@ class Workload:
             self.desc = (f"{name}-shaped random-init {str(dt).split('.')[-1]} linear weights ({len(shapes)} tensors), "
                          "int8-sym per-channel, stats only (per-row/tensor MSE, sum|err|, exact P99 of the per-row MSE)")
             outs = dict(deq=False, codes=False, scale=True, abs_err=None, seg_sse=True, totals=True)
-            self.weights = []
-            for i, (r, c) in enumerate(shapes):
-                g.manual_seed(1000 * rank + i)
-                self.weights.append((torch.randn(r, c, generator=g, device=device) * 0.02).to(dt))
-            for i, w in enumerate(self.weights):
-                self.passes.append((i, w, _lib.INT_SYM, None, None, outs))
-        self.weight_bytes = sum(w.numel() * w.element_size() for _, w, *_ in self.passes)
+            groups = {}
+            for sh in shapes:
+                groups[sh] = groups.get(sh, 0) + 1
+            for k, ((r, c), cnt) in enumerate(groups.items()):
+                for lo in range(0, cnt, 32):
+                    b = min(32, cnt - lo)
+                    g.manual_seed(1000 * rank + 17 * k + lo)
+                    w = (torch.randn(b, r, c, generator=g, device=device) * 0.02).to(dt)
+                    self.batches.append((w, _lib.INT_SYM, None, None, outs))
+        self.tensors = sum(w.shape[0] for w, *_ in self.batches)
+        self.weight_bytes = sum(w.numel() * w.element_size() for w, *_ in self.batches)
         self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f, gs, o)
-                              for _, w, f, _, gs, o in self.passes)
-        self.launches = len(self.passes)
-        self.stats = torch.zeros(len(self.passes), 5, dtype=torch.float64, device=device)
+                              for w, f, _, gs, o in self.batches)
+        self.launches = len(self.batches)
+        self.stats = [torch.zeros(w.shape[0], 5, dtype=torch.float64, device=device) for w, *_ in self.batches]
 
     def step(self):
-        for k, (i, w, fmt, dt, gs, outs) in enumerate(self.passes):
-            # one preallocated output set per pass: outputs cycle through > 256 MiB so they reach HBM
-            res = self.results.get((i, gs))
-            res = qa.quantize(w, fmt, 8, gs, dt, out=res, **outs)
-            self.results[(i, gs)] = res
+        for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
+            # one preallocated output set per batch: outputs cycle through > 256 MiB so they reach HBM
+            res = quantize_batch(w, fmt, 8, gs, dt, out=self.results.get(k), **outs)
+            self.results[k] = res
             rec = self.stats[k]
-            rec[0:2].copy_(res.totals, non_blocking=True)          # sum err^2, sum |err|
-            L = gs if gs else w.shape[1]
-            per_vec = res.seg_sse / L                               # per-(row, group) / per-row MSE vector
-            rec[2] = per_vec.mean()                                 # mse_rep
-            rec[3] = percentile(per_vec, 99)                        # mse_p99 (float64, exact select)
+            rec[:, 0:2] = res.totals                                   # sum err^2, sum |err|
+            # mean and exact P99 (float64 select) of the per-(row, group) / per-row MSE vectors
+            rec[:, 2], rec[:, 3] = vector_mse_stats(res.seg_sse, gs if gs else w.shape[2], 99)
             if res.abs_err is not None:
-                rec[4] = percentile(res.abs_err, 99)                # P99 of |err| (float32, exact select)
+                rec[:, 4] = percentile_batch(res.abs_err.view(w.shape[0], -1), 99)   # P99 of |err| (float32)
         return self.stats
 
 
@@ -164,12 +166,13 @@ def main():
     _lib.lib()
 
     wl = Workload(args.workload, device, rank)
-    gathered = torch.zeros(world, *wl.stats.shape, dtype=torch.float64, device=device) if world > 1 else None
+    gathered = torch.zeros(world, wl.tensors, 5, dtype=torch.float64, device=device) if world > 1 else None
 
     def one_step():
         stats = wl.step()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, stats)  # per-tensor statistics records -> every rank
+            # per-tensor statistics records of every rank -> every rank, one RCCL collective per step
+            dist.all_gather_into_tensor(gathered, torch.cat(stats))
 
     for _ in range(args.warmup):
         one_step()
@@ -194,14 +197,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
 
-    # dominant kernel: back-to-back fused launches only (no stats copies), HIP events on the launch stream
-    reps = 3
+    # dominant kernel: back-to-back fused launches only (no statistics post-processing), HIP events on the
+    # launch stream (torch's current stream is the stream the library launches on)
+    reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        for k, (i, w, fmt, dt, gs, outs) in enumerate(wl.passes):
-            qa.quantize(w, fmt, 8, gs, dt, out=wl.results[(i, gs)], **dict(outs, totals=False))
+        for k, (w, fmt, dt, gs, outs) in enumerate(wl.batches):
+            quantize_batch(w, fmt, 8, gs, dt, out=wl.results[k], **dict(outs, totals=False))
     e1.record()
     torch.cuda.synchronize()
     kern_ms = e0.elapsed_time(e1) / (reps * wl.launches)
@@ -226,13 +230,14 @@ def main():
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl.desc}", "launches_per_step": wl.launches,
+            "config": {"workload": f"{args.workload}: {wl.desc}", "fused_launches_per_step": wl.launches,
+                       "tensor_passes_per_step": wl.tensors,
                        "weight_bytes_per_step_per_gpu": wl.weight_bytes,
                        "algorithmic_bytes_per_step_per_gpu": int(wl.algo_bytes),
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "fused quantize (mq_quantize)", "avg_launch_us": round(kern_ms * 1e3, 2),
+                         "kernel": "fused quantize (mq_quantize_batch: one launch per batch of same-shaped tensors)", "avg_launch_us": round(kern_ms * 1e3, 2),
                          "algorithmic_bytes_per_launch": int(algo_per_launch)},
         }
         if world == 1 and not args.no_cpu_baseline:

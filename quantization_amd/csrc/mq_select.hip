@@ -19,6 +19,18 @@
 // Both order statistics numpy interpolates between (ranks k and k + 1) are tracked, each with its own
 // prefix once they part.  The final interpolation repeats numpy 2.2's arithmetic in the array's dtype.
 // All kernels take a batch of arrays (blockIdx.y = array), each with its own workspace slice.
+//
+// Large float32 arrays (the |error| dumps) take a cheaper route first, the exact one only if it fails:
+//   sample   1/32 of the array (one pseudo-randomly placed 256-byte line of every 8 KiB) goes into a
+//            15-bit histogram; the sample ranks 8 standard deviations either side of the wanted
+//            quantile give a bracket of at most 16 top-level bins;
+//   bracket  ONE pass over the whole array counts the elements below the bracket (registers, no
+//            atomics) and builds the full-resolution histogram of the elements inside it (a fraction
+//            of a percent, aggregated in an LDS hash table);
+//   scan     if both wanted ranks fall inside the bracket their values are exact and final;
+//            otherwise the slice's `ok` flag stays 0 and the exact level-0/level-1 kernels, which are
+//            always enqueued behind and return at once when `ok` is set, produce the result.
+// The bracket is only ever a guess about where to look: the counts that decide are exact.
 #include "mq_common.h"
 
 #define SEL_TOP_BINS 32768
@@ -38,13 +50,26 @@ struct SelLevel {  // histograms of one level >= 1, for the two tracked ranks
   uint32_t fine[2][SEL_DIGIT_BINS];
 };
 
+#define SEL_BR_BINS 16       // widest bracket, in level-0 bins
+#define SEL_BR_HASH 4096
+#define SEL_CHUNK_LINES 32   // one 256-byte line of every 32 is sampled
+#define SEL_BR_MIN_N (1 << 21)
+
 struct SelWs {
   SelState st;
-  uint32_t pad[52];
+  uint32_t br_lo, br_nb;     // bracket: first level-0 bin, number of bins (0: none)
+  uint32_t ok, pad0;         // 1: the bracket pass produced the result
+  unsigned long long below;  // exact number of elements under the bracket
+  uint32_t pad[48];
   uint32_t top_coarse[SEL_TOP_BINS / 256];
   uint32_t top[SEL_TOP_BINS];
   SelLevel lvl[3];  // cleared once per selection, only as many as the dtype needs
+  uint32_t samp_coarse[SEL_TOP_BINS / 256];
+  uint32_t samp[SEL_TOP_BINS];
+  uint32_t br_coarse[SEL_BR_BINS * 256];
+  uint32_t br_fine[SEL_BR_BINS * 65536];
 };
+static_assert(offsetof(SelWs, top_coarse) == 256, "header is 256 bytes");
 
 struct SelBatch {
   const void* x[SEL_MAX_BATCH];
@@ -60,11 +85,26 @@ __device__ __forceinline__ uint64_t key_of(float v) { return (uint64_t)(f_bits(v
 __device__ __forceinline__ uint64_t key_of(double v) { return __builtin_bit_cast(uint64_t, v) & 0x7fffffffffffffffull; }
 
 // ---- level 0 -------------------------------------------------------------------------------------
+// Merges a workgroup's LDS histogram into the global one.  Same-address global atomics serialise in L2, and
+// every workgroup of an array meets in the same few coarse counters: a wave covers 64 consecutive bins that
+// share one coarse counter, so it adds their sum with ONE atomic.
+__device__ __forceinline__ void flush_top(const uint32_t* lh, uint32_t* fine, uint32_t* coarse) {
+  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) {
+    const uint32_t c = lh[i];
+    if (c) atomicAdd(&fine[i], c);
+    uint32_t sum = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&coarse[i >> 8], sum);
+  }
+}
+
 template <typename T>
-__global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b) {
+__global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int guard) {
   extern __shared__ uint32_t lh[];
   const T* x = static_cast<const T*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
+  if (guard && ws->ok) return;
   const int64_t n = b.n;
   for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
   __syncthreads();
@@ -83,13 +123,7 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b) {
   }
   for (int64_t i = nvec * V + t0; i < n; i += step) atomicAdd(&lh[(uint32_t)(key_of(x[i]) >> 48)], 1u);
   __syncthreads();
-  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) {
-    uint32_t c = lh[i];
-    if (c) {
-      atomicAdd(&ws->top[i], c);
-      atomicAdd(&ws->top_coarse[i >> 8], c);
-    }
-  }
+  flush_top(lh, ws->top, ws->top_coarse);
 }
 
 // ---- scan: which bin holds each remaining rank -----------------------------------------------------
@@ -137,12 +171,14 @@ __device__ __forceinline__ void locate(const uint32_t* coarse, const uint32_t* f
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, uint64_t k0, uint64_t k1, FinishArgs fin) {
+__global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, uint64_t k0, uint64_t k1, FinishArgs fin,
+                                                  int guard) {
   __shared__ uint64_t wsum[4];
   __shared__ uint32_t sh_bin;
   __shared__ uint64_t sh_rank;
   __shared__ SelState st;
   SelWs* ws = batch_ws(b, blockIdx.x);
+  if (guard && ws->ok) return;
   if (threadIdx.x == 0) {
     if (level == 0) {  // the ranks arrive with the first scan
       SelState s0 = {};
@@ -194,11 +230,12 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, u
 // first aggregates them in an LDS hash table (linear probing), then merges the table into the global
 // histogram.  A full table (more distinct values than slots) falls back to global atomics.
 template <typename T>
-__global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int level) {
+__global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int level, int guard) {
   __shared__ uint32_t hkey[2][SEL_HASH];  // digit + 1, 0 = empty
   __shared__ uint32_t hcnt[2][SEL_HASH];
   const T* x = static_cast<const T*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
+  if (guard && ws->ok) return;
   SelLevel* lv = &ws->lvl[level - 1];
   const int64_t n = b.n;
   for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) { (&hkey[0][0])[i] = 0; (&hcnt[0][0])[i] = 0; }
@@ -237,13 +274,208 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int le
   }
   for (int64_t i = nvec * V + t0; i < n; i += step) put(key_of(x[i]));
   __syncthreads();
+  // coarse counters meet in LDS first: one global atomic per counter and workgroup
+  __shared__ uint32_t lcoarse[2][SEL_DIGIT_BINS / 256];
+  for (int i = threadIdx.x; i < 2 * (SEL_DIGIT_BINS / 256); i += blockDim.x) (&lcoarse[0][0])[i] = 0;
+  __syncthreads();
   for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) {
     const int s = i / SEL_HASH, h = i % SEL_HASH;
     if (hkey[s][h]) {
       const uint32_t d = hkey[s][h] - 1u;
       atomicAdd(&lv->fine[s][d], hcnt[s][h]);
-      atomicAdd(&lv->coarse[s][d >> 8], hcnt[s][h]);
+      atomicAdd(&lcoarse[s][d >> 8], hcnt[s][h]);
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * (SEL_DIGIT_BINS / 256); i += blockDim.x) {
+    const uint32_t c = (&lcoarse[0][0])[i];
+    if (c) atomicAdd(&(&lv->coarse[0][0])[i], c);
+  }
+}
+
+// ---- sample / bracket route (float32) ----------------------------------------------------------------
+// Clears two byte ranges of every workspace slice (16-byte stores).
+__global__ __launch_bounds__(256) void k_sel_clear(const SelBatch b, uint32_t a_end, uint32_t b_begin, uint32_t b_end) {
+  u32x4* base = reinterpret_cast<u32x4*>(batch_ws(b, blockIdx.y));
+  const u32x4 z = {0, 0, 0, 0};
+  const uint32_t na = a_end / 16, nb0 = b_begin / 16, nb1 = b_end / 16;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += gridDim.x * blockDim.x) base[i] = z;
+  for (uint32_t i = nb0 + blockIdx.x * blockDim.x + threadIdx.x; i < nb1; i += gridDim.x * blockDim.x) base[i] = z;
+}
+
+// Which 256-byte line of 8 KiB chunk c is sampled.
+__device__ __forceinline__ uint32_t sample_line(uint32_t c) { return (c * 0x9E3779B1u) >> 27; }
+
+__global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
+  extern __shared__ uint32_t lh[];
+  const u32x4* x = static_cast<const u32x4*>(b.x[blockIdx.y]);
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const int64_t nchunks = b.n / (SEL_CHUNK_LINES * 64);  // 64 float32 per line
+  const int64_t total = nchunks * 16;                    // 16 lanes x 16 bytes read one line
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  constexpr int U = 8;  // scattered lines: keep 8 loads in flight per lane
+  for (int64_t i0 = t0; i0 < total; i0 += U * step) {
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * step;
+      const int64_t c = i >> 4;
+      raw[u] = u32x4{0, 0, 0, 0};
+      if (i < total) raw[u] = x[c * (SEL_CHUNK_LINES * 16) + sample_line((uint32_t)c) * 16 + ((uint32_t)i & 15u)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * step < total) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&lh[(raw[u][k] >> 16) & 0x7fffu], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  flush_top(lh, ws->samp, ws->samp_coarse);
+}
+
+// Bins of the two sample ranks -> bracket.
+__global__ __launch_bounds__(256) void k_sel_scan_sample(const SelBatch b, uint64_t r_lo, uint64_t r_hi) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint32_t sh_bin;
+  __shared__ uint64_t sh_rank;
+  SelWs* ws = batch_ws(b, blockIdx.x);
+  if (threadIdx.x == 0) { sh_bin = 0; sh_rank = 0; }
+  __syncthreads();
+  locate(ws->samp_coarse, ws->samp, SEL_TOP_BINS / 256, r_lo, wsum, &sh_bin, &sh_rank);
+  const uint32_t lo = sh_bin;
+  __syncthreads();
+  locate(ws->samp_coarse, ws->samp, SEL_TOP_BINS / 256, r_hi, wsum, &sh_bin, &sh_rank);
+  const uint32_t hi = sh_bin;
+  if (threadIdx.x == 0) {
+    const bool usable = hi >= lo && hi - lo < SEL_BR_BINS;
+    ws->br_lo = lo;
+    ws->br_nb = usable ? hi - lo + 1 : 0;
+  }
+}
+
+// Clears the part of the bracket histogram that the bracket found by the sample scan will use.
+__global__ __launch_bounds__(256) void k_sel_clear_bracket(const SelBatch b) {
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  const uint32_t nbins = ws->br_nb;
+  const u32x4 z = {0, 0, 0, 0};
+  u32x4* coarse = reinterpret_cast<u32x4*>(ws->br_coarse);
+  u32x4* fine = reinterpret_cast<u32x4*>(ws->br_fine);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbins * 64; i += gridDim.x * blockDim.x) coarse[i] = z;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbins * 16384; i += gridDim.x * blockDim.x) fine[i] = z;
+}
+
+__global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
+  __shared__ uint32_t hkey[SEL_BR_HASH];  // key + 1, 0 = empty
+  __shared__ uint32_t hcnt[SEL_BR_HASH];
+  __shared__ uint32_t wcnt[4];
+  const u32x4* x = static_cast<const u32x4*>(b.x[blockIdx.y]);
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  const uint32_t lo = ws->br_lo, nbins = ws->br_nb;
+  if (nbins == 0) return;
+  for (int i = threadIdx.x; i < SEL_BR_HASH; i += blockDim.x) { hkey[i] = 0; hcnt[i] = 0; }
+  __syncthreads();
+  uint32_t below = 0;  // per lane: at most n / (grid * 256) + 4 < 2^32
+  auto put = [&](uint32_t bits) {
+    bits &= 0x7fffffffu;
+    const uint32_t t = (bits >> 16) - lo;  // wraps for bins under the bracket
+    below += (bits >> 16) < lo ? 1u : 0u;
+    if (t < nbins) {
+      const uint32_t key = (t << 16) | (bits & 0xffffu);
+      uint32_t h = (key * 2654435761u) >> 20;  // 12 bits
+      for (int probe = 0; probe < 64; ++probe) {
+        uint32_t old = atomicCAS(&hkey[h], 0u, key + 1u);
+        if (old == 0u || old == key + 1u) { atomicAdd(&hcnt[h], 1u); return; }
+        h = (h + 1) & (SEL_BR_HASH - 1);
+      }
+      atomicAdd(&ws->br_fine[key], 1u);
+      atomicAdd(&ws->br_coarse[key >> 8], 1u);
+    }
+  };
+  const int64_t n = b.n, nvec = n / 4;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  int64_t v = t0;
+  for (; v + step < nvec; v += 2 * step) {  // two loads in flight
+    u32x4 r0 = x[v], r1 = x[v + step];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(r0[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(r1[i]);
+  }
+  for (; v < nvec; v += step) {
+    u32x4 r0 = x[v];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(r0[i]);
+  }
+  const uint32_t* xs = static_cast<const uint32_t*>(b.x[blockIdx.y]);
+  for (int64_t i = nvec * 4 + t0; i < n; i += step) put(xs[i]);
+  // block total of `below`
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) below += __shfl_xor(below, off);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = below;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&ws->below, (unsigned long long)wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]);
+  // coarse counters meet in LDS first: one global atomic per counter and workgroup
+  __shared__ uint32_t lcoarse[SEL_BR_BINS * 256];
+  for (int i = threadIdx.x; i < SEL_BR_BINS * 256; i += blockDim.x) lcoarse[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < SEL_BR_HASH; i += blockDim.x) {
+    if (hkey[i]) {
+      const uint32_t key = hkey[i] - 1u;
+      atomicAdd(&ws->br_fine[key], hcnt[i]);
+      atomicAdd(&lcoarse[key >> 8], hcnt[i]);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < nbins * 256; i += blockDim.x) {
+    const uint32_t c = lcoarse[i];
+    if (c) atomicAdd(&ws->br_coarse[i], c);
+  }
+}
+
+// Both ranks inside the bracket -> exact values, interpolation, ok = 1.
+__global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, uint64_t k0, uint64_t k1, FinishArgs fin) {
+  __shared__ uint64_t wsum[4];
+  __shared__ uint32_t sh_bin;
+  __shared__ uint64_t sh_rank;
+  __shared__ uint64_t tot[SEL_BR_BINS + 1];
+  SelWs* ws = batch_ws(b, blockIdx.x);
+  const uint32_t nbins = ws->br_nb;
+  if (nbins == 0) return;
+  if (threadIdx.x == 0) { sh_bin = 0; sh_rank = 0; tot[0] = 0; }
+  for (uint32_t j = 0; j < nbins; ++j) {  // elements per bracket bin
+    uint64_t c = ws->br_coarse[j * 256 + threadIdx.x];
+    uint64_t before = block_excl_scan(c, wsum);
+    if (threadIdx.x == 255) tot[j + 1] = before + c;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    for (uint32_t j = 0; j < nbins; ++j) tot[j + 1] += tot[j];
+  __syncthreads();
+  const uint64_t below = ws->below, inside = tot[nbins];
+  if (k0 < below || k1 >= below + inside) return;  // not resolved here: the exact route runs
+  uint32_t bits[2];
+  for (int r = 0; r < 2; ++r) {
+    const uint64_t rk = (r ? k1 : k0) - below;
+    uint32_t j = 0;
+    while (j + 1 < nbins && rk >= tot[j + 1]) ++j;
+    locate(ws->br_coarse + j * 256, ws->br_fine + j * 65536, 256, rk - tot[j], wsum, &sh_bin, &sh_rank);
+    bits[r] = ((ws->br_lo + j) << 16) | sh_bin;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
+    float g = (float)fin.gamma, diff = c - a;
+    float v = a + diff * g;
+    if (g >= 0.5f) v = c - diff * (1.0f - g);
+    if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
+    if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+    ws->st.prefix[0] = (uint64_t)bits[0] << 32;
+    ws->st.prefix[1] = (uint64_t)bits[1] << 32;
+    ws->ok = 1;
   }
 }
 
@@ -298,7 +530,7 @@ extern "C" int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-static int launch_accumulate(const SelBatch& b, int count, int32_t dtype, int level, hipStream_t st) {
+static int launch_accumulate(const SelBatch& b, int count, int32_t dtype, int level, hipStream_t st, int guard = 0) {
   const int V = dtype == MQ_F32 ? 4 : 2;
   if (level == 0) {
     int64_t nb = (b.n / V + 1024 * 4 - 1) / (1024 * 4);
@@ -307,18 +539,18 @@ static int launch_accumulate(const SelBatch& b, int count, int32_t dtype, int le
     if (dtype == MQ_F32) {
       MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<float>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
-      hipLaunchKernelGGL((k_sel_hist_top<float>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b);
+      hipLaunchKernelGGL((k_sel_hist_top<float>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
     } else {
       MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
-      hipLaunchKernelGGL((k_sel_hist_top<double>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b);
+      hipLaunchKernelGGL((k_sel_hist_top<double>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
     }
   } else {
     int64_t nb = (b.n / V + 256 * 4 - 1) / (256 * 4);
     int64_t cap = 1024 / count < 16 ? 16 : 1024 / count;
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
-    if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_hist_digit<float>), grid, dim3(256), 0, st, b, level);
-    else hipLaunchKernelGGL((k_sel_hist_digit<double>), grid, dim3(256), 0, st, b, level);
+    if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_hist_digit<float>), grid, dim3(256), 0, st, b, level, guard);
+    else hipLaunchKernelGGL((k_sel_hist_digit<double>), grid, dim3(256), 0, st, b, level, guard);
   }
   MQ_HIP(hipGetLastError());
   return MQ_OK;
@@ -359,14 +591,15 @@ extern "C" int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t fin
   b.ws = static_cast<char*>(workspace);
   FinishArgs fin = {finish ? dtype : -1, gamma, static_cast<char*>(out), static_cast<char*>(out_pair)};
   hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, static_cast<hipStream_t>(hip_stream), b, (int)level,
-                     (uint64_t)k0, (uint64_t)k1, fin);
+                     (uint64_t)k0, (uint64_t)k1, fin, 0);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 
 // np.percentile(xs[i], pct) for `count` non-negative arrays of n values each (same dtype), one result per
-// array in out[i] (and out_pair[2 i], out_pair[2 i + 1]): 5 launches per 32 arrays for float32 (fill,
-// histogram, scan, matched-digit histogram, scan + interpolation), 9 for float64.  xs is a HOST array.
+// array in out[i] (and out_pair[2 i], out_pair[2 i + 1]): 5 launches per 32 arrays for float32 (clear,
+// histogram, scan, matched-digit histogram, scan + interpolation), 9 for float64, 5 more in front for
+// float32 arrays of 2^21 values and up (sample, bracket: 5 launches).  xs is a HOST array.
 extern "C" int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct,
                                    void* out, void* out_pair, void* workspace, size_t workspace_bytes,
                                    void* hip_stream) {
@@ -394,19 +627,47 @@ extern "C" int mq_percentile_batch(const void* const* xs, int32_t count, int32_t
     b.ws = static_cast<char*>(workspace);
     b.ws_stride = (int64_t)sizeof(SelWs);
     b.n = n;
-    // one fill per slice would be c launches: the slices are contiguous, clear them together up to the
-    // last level this dtype uses
-    if (ws_used_bytes(dtype) == sizeof(SelWs) || c == 1) {
-      MQ_HIP(hipMemsetAsync(workspace, 0, (size_t)(c - 1) * sizeof(SelWs) + ws_used_bytes(dtype), st));
-    } else {
-      MQ_HIP(hipMemset2DAsync(workspace, sizeof(SelWs), 0, ws_used_bytes(dtype), (size_t)c, st));
+    // sample ranks 8 standard deviations either side of the wanted quantile (m sampled elements)
+    const int64_t m = n / (SEL_CHUNK_LINES * 64) * 64;
+    bool bracket = dtype == MQ_F32 && n >= SEL_BR_MIN_N;
+    double r_lo = 0, r_hi = 0;
+    if (bracket) {
+      const double frac = (double)m / (double)n, p = ((double)k0 + 0.5) / (double)n;
+      const double margin = 8.0 * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
+      r_lo = __builtin_floor((double)k0 * frac) - margin;
+      r_hi = __builtin_ceil((double)k1 * frac) + margin;
+      bracket = r_lo >= 0.0 && r_hi <= (double)(m - 1);  // quantiles at the very ends: exact route only
     }
+    // clear what this selection accumulates into: header + level histograms, and the sample / bracket area
+    const uint32_t a_end = (uint32_t)ws_used_bytes(dtype);
+    const uint32_t b_begin = bracket ? (uint32_t)offsetof(SelWs, samp_coarse) : 0u;
+    const uint32_t b_end = bracket ? (uint32_t)offsetof(SelWs, br_coarse) : 0u;
+    hipLaunchKernelGGL(k_sel_clear, dim3((unsigned)(1024 / c < 8 ? 8 : 1024 / c), (unsigned)c), dim3(256), 0, st, b, a_end,
+                       b_begin, b_end);
+    MQ_HIP(hipGetLastError());
+    FinishArgs fin_last = {dtype, gamma, out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
+                           out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr};
+    if (bracket) {
+      int64_t nb = (m / 4 + 1024 * 8 - 1) / (1024 * 8);
+      int64_t cap = 256 / c < 2 ? 2 : 256 / c;
+      MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 SEL_TOP_BINS * 4));
+      hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(1024),
+                         SEL_TOP_BINS * 4, st, b);
+      hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)c), dim3(256), 0, st, b, (uint64_t)r_lo, (uint64_t)r_hi);
+      hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / c < 8 ? 8 : 512 / c), (unsigned)c), dim3(256), 0, st, b);
+      nb = (n / 4 + 256 * 8 - 1) / (256 * 8);
+      cap = 2048 / c < 16 ? 16 : 2048 / c;
+      hipLaunchKernelGGL(k_sel_bracket, dim3((unsigned)(nb > cap ? cap : nb), (unsigned)c), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, (uint64_t)k0, (uint64_t)k1, fin_last);
+      MQ_HIP(hipGetLastError());
+    }
+    const int guard = bracket ? 1 : 0;  // the exact route returns at once for slices the bracket resolved
     for (int level = 0; level <= levels; ++level) {
-      if ((rc = launch_accumulate(b, c, dtype, level, st))) return rc;
-      FinishArgs fin = {level == levels ? dtype : -1, gamma,
-                        out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
-                        out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr};
-      hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)c), dim3(256), 0, st, b, level, (uint64_t)k0, (uint64_t)k1, fin);
+      if ((rc = launch_accumulate(b, c, dtype, level, st, guard))) return rc;
+      FinishArgs fin = fin_last;
+      if (level != levels) fin.dtype = -1;
+      hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)c), dim3(256), 0, st, b, level, (uint64_t)k0, (uint64_t)k1, fin, guard);
       MQ_HIP(hipGetLastError());
     }
   }

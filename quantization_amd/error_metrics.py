@@ -94,6 +94,24 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
 
 
 @torch.no_grad()
+def vector_mse_stats(seg_sse: torch.Tensor, seg_len: int, pct: float = 99.0):
+    """(mean, percentile) of the per-vector MSE list seg_sse[i, :] / seg_len for every row i of a [B, nseg]
+    float64 tensor of squared-error sums -- the `mse_rep` / `mse_p99` pair of
+    quant_error_multi_weight.py:84-85 and quant_error_single_weight.py:78-79.
+
+    For a power-of-two seg_len the division is an exponent shift, which commutes exactly with the order
+    statistics and with numpy's interpolation, so the select runs on the sums themselves and only the B
+    results are divided; any other length divides the whole list first, as the scripts do."""
+    if seg_sse.dim() != 2 or seg_sse.dtype != torch.float64:
+        raise ValueError("vector_mse_stats() takes a [B, nseg] float64 tensor")
+    L = int(seg_len)
+    if L > 0 and (L & (L - 1)) == 0:
+        return seg_sse.mean(dim=1) / L, percentile_batch(seg_sse, pct) / L
+    per_vec = seg_sse / L
+    return per_vec.mean(dim=1), percentile_batch(per_vec, pct)
+
+
+@torch.no_grad()
 def error_stats(a: torch.Tensor, b: torch.Tensor, seg_len: Optional[int] = None, abs_err=None,
                 cols: bool = False, totals: bool = True):
     """One pass over (a, b): dict with 'totals' ([sum err^2, sum |err|], float64), 'seg_sse' (row-form sums

@@ -160,3 +160,36 @@ def test_percentile_batch(em, dtype):
         got = em.percentile_batch(torch.from_numpy(arr).cuda(), 99).cpu().numpy()
         want = np.array([np.percentile(arr[i], 99) for i in range(B)], dtype)
         assert got.tobytes() == want.tobytes(), (B, n)
+
+
+def test_percentile_sample_route_falls_back(em):
+    """Large float32 arrays are located through a 1/32 sample first (one 256-byte line of every 8 KiB, line
+    index = top 5 bits of chunk * 0x9E3779B1).  An array whose sampled lines are all zero makes the sample
+    point at the wrong place; the exact route behind it must still give numpy's bits."""
+    rng = np.random.default_rng(77)
+    n = (1 << 22) + 12345
+    arr = np.abs(rng.standard_normal(n)).astype(np.float32)
+    chunks = np.arange(n // 2048, dtype=np.uint64)
+    line = ((chunks * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(27)
+    start = (chunks * np.uint64(2048) + line * np.uint64(64)).astype(np.int64)
+    idx = (start[:, None] + np.arange(64)[None, :]).ravel()
+    fooled = arr.copy()
+    fooled[idx] = 0
+    x = torch.from_numpy(np.stack([arr[: 1 << 22], fooled[: 1 << 22]])).cuda()
+    got = em.percentile_batch(x, 99).cpu().numpy()
+    want = np.array([np.percentile(arr[: 1 << 22], 99), np.percentile(fooled[: 1 << 22], 99)], np.float32)
+    assert got.tobytes() == want.tobytes()
+    for a in (arr, fooled):
+        for pct in (99, 50, 1, 99.99):
+            got = em.percentile(torch.from_numpy(a).cuda(), pct).cpu().numpy()
+            assert got.tobytes() == np.float32(np.percentile(a, pct)).tobytes(), pct
+
+
+def test_vector_mse_stats(em):
+    rng = np.random.default_rng(4)
+    sse = (rng.random((3, 4096)) ** 4 * 1e-6).astype(np.float64)
+    for L in (32, 128, 96, 4096):
+        mean, p99 = em.vector_mse_stats(torch.from_numpy(sse).cuda(), L)
+        vec = sse / L
+        assert p99.cpu().numpy().tobytes() == np.array([np.percentile(v, 99) for v in vec]).tobytes(), L
+        np.testing.assert_allclose(mean.cpu().numpy(), vec.mean(1), rtol=1e-12)
