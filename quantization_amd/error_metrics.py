@@ -93,6 +93,12 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
     return out
 
 
+def true_div(x: torch.Tensor, d) -> torch.Tensor:
+    """x / d as an IEEE division per element.  (torch turns `tensor / python_scalar` on the device into a
+    multiplication by the rounded reciprocal, which is off by one ulp for some elements.)"""
+    return x / torch.full((), d, dtype=x.dtype, device=x.device)
+
+
 @torch.no_grad()
 def vector_mse_stats(seg_sse: torch.Tensor, seg_len: int, pct: float = 99.0):
     """(mean, percentile) of the per-vector MSE list seg_sse[i, :] / seg_len for every row i of a [B, nseg]
@@ -106,8 +112,8 @@ def vector_mse_stats(seg_sse: torch.Tensor, seg_len: int, pct: float = 99.0):
         raise ValueError("vector_mse_stats() takes a [B, nseg] float64 tensor")
     L = int(seg_len)
     if L > 0 and (L & (L - 1)) == 0:
-        return seg_sse.mean(dim=1) / L, percentile_batch(seg_sse, pct) / L
-    per_vec = seg_sse / L
+        return seg_sse.mean(dim=1) / L, percentile_batch(seg_sse, pct) / L  # exponent shifts: exact
+    per_vec = true_div(seg_sse, L)
     return per_vec.mean(dim=1), percentile_batch(per_vec, pct)
 
 
@@ -175,11 +181,11 @@ def compute_errors(a, b, grouping: str, gs: Optional[int], form: str = "multi", 
         if form == "multi":
             st = error_stats(a, b, cols=True)
             col = st["col_sse"]
-            per_vec = col / K if grouping == "per-channel" else col.reshape(C // gs, gs).sum(dim=1) / (K * gs)
+            per_vec = true_div(col, K) if grouping == "per-channel" else true_div(col.reshape(C // gs, gs).sum(dim=1), K * gs)
         else:
             L = C if grouping == "per-channel" else gs
             st = error_stats(a, b, seg_len=L)
-            per_vec = st["seg_sse"] / L
+            per_vec = true_div(st["seg_sse"], L)
     else:
         st = error_stats(a, b)
     result = {"mse_tensor": float(st["totals"][0].item() / a.numel())}

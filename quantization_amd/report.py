@@ -8,7 +8,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .error_metrics import error_stats, percentile
+from .error_metrics import error_stats, percentile, true_div
 from .fused import LUT_FORMATS, quantize
 
 MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
@@ -68,10 +68,10 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
     rec[0] = w.numel()
     rec[1:3] = res.totals
     if form == "single":
-        per_vec = res.seg_sse / L
+        per_vec = true_div(res.seg_sse, L)
     else:
         col = error_stats(w.half() if w.dtype != torch.float16 else w, res.deq, cols=True, totals=False)["col_sse"]
-        per_vec = col / K if L == C else col.reshape(C // L, L).sum(dim=1) / (K * L)
+        per_vec = true_div(col, K) if L == C else true_div(col.reshape(C // L, L).sum(dim=1), K * L)
     rec[3] = per_vec.mean()
     rec[4] = percentile(per_vec, 99)
     if abs_p99:
