@@ -107,7 +107,9 @@ size_t mq_percentile_workspace_bytes(void);
 /*
  * np.percentile(x, pct) with the default 'linear' method for a NON-NEGATIVE float32 (MQ_F32) or float64
  * (MQ_F64) array of n values in device memory (the sign bit is ignored), computed exactly by radix
- * select on the float bit patterns: 2 passes over a float32 array, 4 over a float64 one.  Replaces
+ * select on the float bit patterns: 2 passes over a float32 array, 4 over a float64 one; float32 arrays of
+ * 2^21 values and more are first tried with a 1/32 sample + ONE counting pass over a bracket around the
+ * wanted ranks (exact whenever both ranks fall inside, otherwise the two-pass route runs).  Replaces
  *   np.percentile(abs_err, 99)  elwise_error/onnx_error_cli.py:113-114   (float32, K*C values)
  *   np.percentile(vec, 99)      MSE&P99/quant_error_multi_weight.py:85, quant_error_single_weight.py:79
  *                               (float64 per-vector MSE list)

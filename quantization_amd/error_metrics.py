@@ -111,10 +111,17 @@ def vector_mse_stats(seg_sse: torch.Tensor, seg_len: int, pct: float = 99.0):
     if seg_sse.dim() != 2 or seg_sse.dtype != torch.float64:
         raise ValueError("vector_mse_stats() takes a [B, nseg] float64 tensor")
     L = int(seg_len)
+    B, nseg = seg_sse.shape
+
+    def row_mean(t):  # mean of equal-sized chunk means: many workgroups per row instead of one
+        if nseg % 256 == 0 and nseg >= 65536:
+            return t.reshape(B * 256, nseg // 256).mean(dim=1).view(B, 256).mean(dim=1)
+        return t.mean(dim=1)
+
     if L > 0 and (L & (L - 1)) == 0:
-        return seg_sse.mean(dim=1) / L, percentile_batch(seg_sse, pct) / L  # exponent shifts: exact
+        return row_mean(seg_sse) / L, percentile_batch(seg_sse, pct) / L  # exponent shifts: exact
     per_vec = true_div(seg_sse, L)
-    return per_vec.mean(dim=1), percentile_batch(per_vec, pct)
+    return row_mean(per_vec), percentile_batch(per_vec, pct)
 
 
 @torch.no_grad()
