@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 import quantization_amd as qa  # noqa: E402
 from quantization_amd import _lib  # noqa: E402
-from quantization_amd.error_metrics import percentile_batch, vector_mse_stats  # noqa: E402
+from quantization_amd.error_metrics import percentile_multi, vector_mse_stats  # noqa: E402
 from quantization_amd.fused import quantize_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
@@ -99,20 +99,42 @@ class Workload:
         self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f, gs, o)
                               for w, f, _, gs, o in self.batches)
         self.launches = len(self.batches)
-        self.stats = [torch.zeros(w.shape[0], 5, dtype=torch.float64, device=device) for w, *_ in self.batches]
+        self.device = device
+        self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
 
     def step(self):
+        """All fused quantize launches of the step, then ONE set of select launches per dtype for the P99s of
+        every tensor of the step (the chains of short kernels run once per step, not once per batch)."""
+        results = []
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
             # one preallocated output set per batch: outputs cycle through > 256 MiB so they reach HBM
             res = quantize_batch(w, fmt, 8, gs, dt, out=self.results.get(k), **outs)
             self.results[k] = res
-            rec = self.stats[k]
-            rec[:, 0:2] = res.totals                                   # sum err^2, sum |err|
-            # mean and exact P99 (float64 select) of the per-(row, group) / per-row MSE vectors
-            rec[:, 2], rec[:, 3] = vector_mse_stats(res.seg_sse, gs if gs else w.shape[2], 99)
+            results.append(res)
+        rec, row = self.record, 0
+        vecs, lens, errs = [], [], []
+        for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
+            B, L = w.shape[0], (gs if gs else w.shape[2])
+            rec[row:row + B, 0:2] = res.totals                          # sum err^2, sum |err|
+            # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
+            rec[row:row + B, 2] = res.totals[:, 0] / (L * res.nseg)
+            vecs += [res.seg_sse[i] for i in range(B)]
+            lens += [L] * B
             if res.abs_err is not None:
-                rec[:, 4] = percentile_batch(res.abs_err.view(w.shape[0], -1), 99)   # P99 of |err| (float32)
-        return self.stats
+                errs += [res.abs_err[i] for i in range(B)]
+            row += B
+        # exact P99 of every per-vector MSE list (float64 select); L is a power of two or the division is
+        # applied to the list first (vector_mse_stats does the latter per batch)
+        if all(L & (L - 1) == 0 for L in lens):
+            rec[:, 3] = percentile_multi(vecs, 99) / torch.tensor(lens, dtype=torch.float64, device=self.device)
+        else:
+            row = 0
+            for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
+                rec[row:row + w.shape[0], 3] = vector_mse_stats(res.seg_sse, gs if gs else w.shape[2], 99)[1]
+                row += w.shape[0]
+        if errs:
+            rec[:len(errs), 4] = percentile_multi(errs, 99)              # exact P99 of |err| (float32 select)
+        return [rec]
 
 
 def cpu_baseline(nthreads):

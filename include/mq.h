@@ -122,10 +122,14 @@ int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out
 
 /*
  * mq_percentile for `count` arrays of n values each (one dtype): out[i] (and out_pair[2 i], [2 i + 1])
- * receive array i's result.  One set of launches per 32 arrays (blockIdx.y = array), each array with its
+ * receive array i's result.  One set of launches per 64 arrays (blockIdx.y = array), each array with its
  * own slice of the workspace.  xs is a HOST array of device pointers, each 16-byte aligned.
  */
 size_t mq_percentile_batch_workspace_bytes(int32_t count);
+/* The same for arrays of different lengths ns[i] (HOST array); arrays travel 64 per set of launches, the
+ * workspace needs mq_percentile_batch_workspace_bytes(min(count, 64)). */
+int mq_percentile_multi(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype, double pct, void* out,
+                        void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct, void* out,
                         void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 

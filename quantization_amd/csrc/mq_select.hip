@@ -36,7 +36,7 @@
 #define SEL_TOP_BINS 32768
 #define SEL_DIGIT_BINS 65536
 #define SEL_HASH 2048
-#define SEL_MAX_BATCH 32
+#define SEL_MAX_BATCH 64
 
 struct SelState {
   uint64_t prefix[2];  // resolved high bits of the two keys, left-aligned in 63 bits
@@ -73,9 +73,16 @@ static_assert(offsetof(SelWs, top_coarse) == 256, "header is 256 bytes");
 
 struct SelBatch {
   const void* x[SEL_MAX_BATCH];
+  int64_t n[SEL_MAX_BATCH];  // values per array
   char* ws;          // SelWs of array 0
   int64_t ws_stride; // bytes between workspace slices (0: all arrays accumulate into one selection)
-  int64_t n;
+};
+struct SelRanks {  // per array: the two wanted ranks and numpy's interpolation weight
+  uint64_t k0[SEL_MAX_BATCH], k1[SEL_MAX_BATCH];
+  double gamma[SEL_MAX_BATCH];
+};
+struct SelSampleRanks {  // per array: sample ranks that bracket the wanted quantile
+  uint64_t lo[SEL_MAX_BATCH], hi[SEL_MAX_BATCH];
 };
 __device__ __forceinline__ SelWs* batch_ws(const SelBatch& b, int y) {
   return reinterpret_cast<SelWs*>(b.ws + (int64_t)y * b.ws_stride);
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
   const T* x = static_cast<const T*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
   if (guard && ws->ok) return;
-  const int64_t n = b.n;
+  const int64_t n = b.n[blockIdx.y];
   for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
@@ -133,7 +140,6 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
 //   r = a + (b - a) * t;  where t >= 0.5:  r = b - (b - a) * (1 - t)
 struct FinishArgs {
   int32_t dtype;  // -1: no finish here; MQ_F32 / MQ_F64
-  double gamma;
   char* out;       // [batch] values of dtype
   char* out_pair;  // [batch][2]
 };
@@ -171,7 +177,7 @@ __device__ __forceinline__ void locate(const uint32_t* coarse, const uint32_t* f
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, uint64_t k0, uint64_t k1, FinishArgs fin,
+__global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, const SelRanks rk, FinishArgs fin,
                                                   int guard) {
   __shared__ uint64_t wsum[4];
   __shared__ uint32_t sh_bin;
@@ -182,8 +188,8 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, u
   if (threadIdx.x == 0) {
     if (level == 0) {  // the ranks arrive with the first scan
       SelState s0 = {};
-      s0.rank[0] = k0;
-      s0.rank[1] = k1;
+      s0.rank[0] = rk.k0[blockIdx.x];
+      s0.rank[1] = rk.k1[blockIdx.x];
       s0.same = 1;
       st = s0;
     } else {
@@ -209,14 +215,14 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, u
     ws->st = res;
     if (fin.dtype == MQ_F32) {
       float a = f_from_bits((uint32_t)(res.prefix[0] >> 32)), c = f_from_bits((uint32_t)(res.prefix[1] >> 32));
-      float g = (float)fin.gamma, diff = c - a;
+      float g = (float)rk.gamma[blockIdx.x], diff = c - a;
       float v = a + diff * g;
       if (g >= 0.5f) v = c - diff * (1.0f - g);
       if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
       if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
     } else if (fin.dtype == MQ_F64) {
       double a = __builtin_bit_cast(double, res.prefix[0]), c = __builtin_bit_cast(double, res.prefix[1]);
-      double g = fin.gamma, diff = c - a;
+      double g = rk.gamma[blockIdx.x], diff = c - a;
       double v = a + diff * g;
       if (g >= 0.5) v = c - diff * (1.0 - g);
       if (fin.out) reinterpret_cast<double*>(fin.out)[blockIdx.x] = v;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int le
   SelWs* ws = batch_ws(b, blockIdx.y);
   if (guard && ws->ok) return;
   SelLevel* lv = &ws->lvl[level - 1];
-  const int64_t n = b.n;
+  const int64_t n = b.n[blockIdx.y];
   for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) { (&hkey[0][0])[i] = 0; (&hcnt[0][0])[i] = 0; }
   __syncthreads();
   const int shift = 48 - 16 * level;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
   SelWs* ws = batch_ws(b, blockIdx.y);
   for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
   __syncthreads();
-  const int64_t nchunks = b.n / (SEL_CHUNK_LINES * 64);  // 64 float32 per line
+  const int64_t nchunks = b.n[blockIdx.y] / (SEL_CHUNK_LINES * 64);  // 64 float32 per line
   const int64_t total = nchunks * 16;                    // 16 lanes x 16 bytes read one line
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   constexpr int U = 8;  // scattered lines: keep 8 loads in flight per lane
@@ -338,7 +344,8 @@ __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
 }
 
 // Bins of the two sample ranks -> bracket.
-__global__ __launch_bounds__(256) void k_sel_scan_sample(const SelBatch b, uint64_t r_lo, uint64_t r_hi) {
+__global__ __launch_bounds__(256) void k_sel_scan_sample(const SelBatch b, const SelSampleRanks sr) {
+  const uint64_t r_lo = sr.lo[blockIdx.x], r_hi = sr.hi[blockIdx.x];
   __shared__ uint64_t wsum[4];
   __shared__ uint32_t sh_bin;
   __shared__ uint64_t sh_rank;
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
       atomicAdd(&ws->br_coarse[key >> 8], 1u);
     }
   };
-  const int64_t n = b.n, nvec = n / 4;
+  const int64_t n = b.n[blockIdx.y], nvec = n / 4;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   int64_t v = t0;
   for (; v + step < nvec; v += 2 * step) {  // two loads in flight
@@ -437,7 +444,8 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
 }
 
 // Both ranks inside the bracket -> exact values, interpolation, ok = 1.
-__global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, uint64_t k0, uint64_t k1, FinishArgs fin) {
+__global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+  const uint64_t k0 = rk.k0[blockIdx.x], k1 = rk.k1[blockIdx.x];
   __shared__ uint64_t wsum[4];
   __shared__ uint32_t sh_bin;
   __shared__ uint64_t sh_rank;
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, uint
   }
   if (threadIdx.x == 0) {
     float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
-    float g = (float)fin.gamma, diff = c - a;
+    float g = (float)rk.gamma[blockIdx.x], diff = c - a;
     float v = a + diff * g;
     if (g >= 0.5f) v = c - diff * (1.0f - g);
     if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
@@ -530,10 +538,24 @@ extern "C" int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-static int launch_accumulate(const SelBatch& b, int count, int32_t dtype, int level, hipStream_t st, int guard = 0) {
+// Sample ranks 8 standard deviations either side of the wanted quantile among the m sampled elements of an
+// array of n; false when the array is too small or the quantile too near an end for the bracket route.
+static bool bracket_ranks(int64_t n, int64_t k0, int64_t k1, int64_t* m_out, double* r_lo, double* r_hi) {
+  if (n < SEL_BR_MIN_N) return false;
+  const int64_t m = n / (SEL_CHUNK_LINES * 64) * 64;
+  const double frac = (double)m / (double)n, p = ((double)k0 + 0.5) / (double)n;
+  const double margin = 8.0 * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
+  *r_lo = __builtin_floor((double)k0 * frac) - margin;
+  *r_hi = __builtin_ceil((double)k1 * frac) + margin;
+  *m_out = m;
+  return *r_lo >= 0.0 && *r_hi <= (double)(m - 1);
+}
+
+static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t dtype, int level, hipStream_t st,
+                             int guard = 0) {
   const int V = dtype == MQ_F32 ? 4 : 2;
   if (level == 0) {
-    int64_t nb = (b.n / V + 1024 * 4 - 1) / (1024 * 4);
+    int64_t nb = (nmax / V + 1024 * 4 - 1) / (1024 * 4);
     int64_t cap = 256 / count < 4 ? 4 : 256 / count;  // one 128 KiB-LDS workgroup fits per CU
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
     if (dtype == MQ_F32) {
@@ -546,7 +568,7 @@ static int launch_accumulate(const SelBatch& b, int count, int32_t dtype, int le
       hipLaunchKernelGGL((k_sel_hist_top<double>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
     }
   } else {
-    int64_t nb = (b.n / V + 256 * 4 - 1) / (256 * 4);
+    int64_t nb = (nmax / V + 256 * 4 - 1) / (256 * 4);
     int64_t cap = 1024 / count < 16 ? 16 : 1024 / count;
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
     if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_hist_digit<float>), grid, dim3(256), 0, st, b, level, guard);
@@ -573,9 +595,9 @@ extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int
   if (n == 0) return MQ_OK;
   SelBatch b = {};
   b.x[0] = x;
+  b.n[0] = n;
   b.ws = static_cast<char*>(workspace);
-  b.n = n;
-  return launch_accumulate(b, 1, dtype, level, static_cast<hipStream_t>(hip_stream));
+  return launch_accumulate(b, 1, n, dtype, level, static_cast<hipStream_t>(hip_stream));
 }
 
 // Step 3 / 5: locate the ranks in the (merged) histogram of `level` and extend the prefixes.  The ranks
@@ -589,87 +611,135 @@ extern "C" int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t fin
   if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
   SelBatch b = {};
   b.ws = static_cast<char*>(workspace);
-  FinishArgs fin = {finish ? dtype : -1, gamma, static_cast<char*>(out), static_cast<char*>(out_pair)};
-  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, static_cast<hipStream_t>(hip_stream), b, (int)level,
-                     (uint64_t)k0, (uint64_t)k1, fin, 0);
+  SelRanks rk = {};
+  rk.k0[0] = (uint64_t)k0;
+  rk.k1[0] = (uint64_t)k1;
+  rk.gamma[0] = gamma;
+  FinishArgs fin = {finish ? dtype : -1, static_cast<char*>(out), static_cast<char*>(out_pair)};
+  hipLaunchKernelGGL(k_sel_scan, dim3(1), dim3(256), 0, static_cast<hipStream_t>(hip_stream), b, (int)level, rk, fin, 0);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 
-// np.percentile(xs[i], pct) for `count` non-negative arrays of n values each (same dtype), one result per
-// array in out[i] (and out_pair[2 i], out_pair[2 i + 1]): 5 launches per 32 arrays for float32 (clear,
-// histogram, scan, matched-digit histogram, scan + interpolation), 9 for float64, 5 more in front for
-// float32 arrays of 2^21 values and up (sample, bracket: 5 launches).  xs is a HOST array.
-extern "C" int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct,
+// One group of <= 64 arrays that all take the same route.
+static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t dtype, double pct, bool bracket,
+                        char* out, char* out_pair, void* workspace, hipStream_t st) {
+  SelBatch b = {};
+  SelRanks rk = {};
+  SelSampleRanks sr = {};
+  int64_t nmax = 0, mmax = 0;
+  for (int i = 0; i < c; ++i) {
+    b.x[i] = xs[i];
+    b.n[i] = ns[i];
+    nmax = ns[i] > nmax ? ns[i] : nmax;
+    int64_t k0, k1;
+    int rc = mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &rk.gamma[i]);
+    if (rc) return rc;
+    rk.k0[i] = (uint64_t)k0;
+    rk.k1[i] = (uint64_t)k1;
+    if (bracket) {
+      double lo, hi;
+      int64_t m;
+      if (!bracket_ranks(ns[i], k0, k1, &m, &lo, &hi)) return MQ_ERR_ARG;  // grouping bug
+      sr.lo[i] = (uint64_t)lo;
+      sr.hi[i] = (uint64_t)hi;
+      mmax = m > mmax ? m : mmax;
+    }
+  }
+  b.ws = static_cast<char*>(workspace);
+  b.ws_stride = (int64_t)sizeof(SelWs);
+  const int levels = dtype == MQ_F32 ? 1 : 3;
+  // clear what this selection accumulates into: header + level histograms, and the sample area
+  const uint32_t a_end = (uint32_t)ws_used_bytes(dtype);
+  const uint32_t b_begin = bracket ? (uint32_t)offsetof(SelWs, samp_coarse) : 0u;
+  const uint32_t b_end = bracket ? (uint32_t)offsetof(SelWs, br_coarse) : 0u;
+  hipLaunchKernelGGL(k_sel_clear, dim3((unsigned)(1024 / c < 8 ? 8 : 1024 / c), (unsigned)c), dim3(256), 0, st, b, a_end,
+                     b_begin, b_end);
+  MQ_HIP(hipGetLastError());
+  FinishArgs fin_last = {dtype, out, out_pair};
+  if (bracket) {
+    int64_t nb = (mmax / 4 + 1024 * 8 - 1) / (1024 * 8);
+    int64_t cap = 256 / c < 2 ? 2 : 256 / c;
+    MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SEL_TOP_BINS * 4));
+    hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(1024),
+                       SEL_TOP_BINS * 4, st, b);
+    hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)c), dim3(256), 0, st, b, sr);
+    hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / c < 8 ? 8 : 512 / c), (unsigned)c), dim3(256), 0, st, b);
+    nb = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
+    cap = 2048 / c < 16 ? 16 : 2048 / c;
+    hipLaunchKernelGGL(k_sel_bracket, dim3((unsigned)(nb > cap ? cap : nb), (unsigned)c), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, rk, fin_last);
+    MQ_HIP(hipGetLastError());
+  }
+  const int guard = bracket ? 1 : 0;  // the exact route returns at once for slices the bracket resolved
+  for (int level = 0; level <= levels; ++level) {
+    int rc = launch_accumulate(b, c, nmax, dtype, level, st, guard);
+    if (rc) return rc;
+    FinishArgs fin = fin_last;
+    if (level != levels) fin.dtype = -1;
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)c), dim3(256), 0, st, b, level, rk, fin, guard);
+    MQ_HIP(hipGetLastError());
+  }
+  return MQ_OK;
+}
+
+// np.percentile(xs[i], pct) for `count` non-negative arrays of ns[i] values (one dtype), one result per
+// array in out[i] (and out_pair[2 i], out_pair[2 i + 1]).  Arrays travel in groups of <= 64 per set of
+// launches: 5 launches for float32 (clear, histogram, scan, matched-digit histogram, scan + interpolation),
+// 9 for float64; float32 arrays of 2^21 values and more go first through sample + bracket (5 launches in
+// front).  xs and ns are HOST arrays.
+extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype, double pct,
                                    void* out, void* out_pair, void* workspace, size_t workspace_bytes,
                                    void* hip_stream) {
-  if (count < 0 || (count > 0 && !xs) || n <= 0 || (!out && !out_pair)) return MQ_ERR_ARG;
+  if (count < 0 || (count > 0 && (!xs || !ns)) || (!out && !out_pair)) return MQ_ERR_ARG;
   if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
   if (count == 0) return MQ_OK;
   if (!workspace || workspace_bytes < mq_percentile_batch_workspace_bytes(count > SEL_MAX_BATCH ? SEL_MAX_BATCH : count))
     return MQ_ERR_WORKSPACE;
   if (!al16(workspace)) return MQ_ERR_ALIGN;
   for (int i = 0; i < count; ++i) {
-    if (!xs[i]) return MQ_ERR_ARG;
+    if (!xs[i] || ns[i] <= 0) return MQ_ERR_ARG;
     if (!al16(xs[i])) return MQ_ERR_ALIGN;
   }
-  int64_t k0, k1;
-  double gamma;
-  int rc = mq_percentile_index(dtype, n, pct, &k0, &k1, &gamma);
-  if (rc) return rc;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const size_t esz = dtype == MQ_F32 ? 4 : 8;
-  const int levels = dtype == MQ_F32 ? 1 : 3;
+  // consecutive arrays that take the same route form a group
+  auto route = [&](int i) {
+    int64_t k0, k1, m;
+    double g, lo, hi;
+    if (mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &g)) return false;
+    return dtype == MQ_F32 && bracket_ranks(ns[i], k0, k1, &m, &lo, &hi);
+  };
+  int done = 0;
+  while (done < count) {
+    const bool br = route(done);
+    int c = 1;
+    while (done + c < count && c < SEL_MAX_BATCH && route(done + c) == br) ++c;
+    int rc = select_group(xs + done, ns + done, c, dtype, pct, br,
+                          out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
+                          out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr, workspace, st);
+    if (rc) return rc;
+    done += c;
+  }
+  return MQ_OK;
+}
+
+// The same for arrays of one length.
+extern "C" int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct,
+                                   void* out, void* out_pair, void* workspace, size_t workspace_bytes,
+                                   void* hip_stream) {
+  if (count < 0 || n <= 0) return MQ_ERR_ARG;
+  int64_t ns[SEL_MAX_BATCH];
+  for (int i = 0; i < SEL_MAX_BATCH; ++i) ns[i] = n;
+  const size_t esz = dtype == MQ_F32 ? 4 : 8;
   for (int done = 0; done < count; done += SEL_MAX_BATCH) {
     const int c = count - done < SEL_MAX_BATCH ? count - done : SEL_MAX_BATCH;
-    SelBatch b = {};
-    for (int i = 0; i < c; ++i) b.x[i] = xs[done + i];
-    b.ws = static_cast<char*>(workspace);
-    b.ws_stride = (int64_t)sizeof(SelWs);
-    b.n = n;
-    // sample ranks 8 standard deviations either side of the wanted quantile (m sampled elements)
-    const int64_t m = n / (SEL_CHUNK_LINES * 64) * 64;
-    bool bracket = dtype == MQ_F32 && n >= SEL_BR_MIN_N;
-    double r_lo = 0, r_hi = 0;
-    if (bracket) {
-      const double frac = (double)m / (double)n, p = ((double)k0 + 0.5) / (double)n;
-      const double margin = 8.0 * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
-      r_lo = __builtin_floor((double)k0 * frac) - margin;
-      r_hi = __builtin_ceil((double)k1 * frac) + margin;
-      bracket = r_lo >= 0.0 && r_hi <= (double)(m - 1);  // quantiles at the very ends: exact route only
-    }
-    // clear what this selection accumulates into: header + level histograms, and the sample / bracket area
-    const uint32_t a_end = (uint32_t)ws_used_bytes(dtype);
-    const uint32_t b_begin = bracket ? (uint32_t)offsetof(SelWs, samp_coarse) : 0u;
-    const uint32_t b_end = bracket ? (uint32_t)offsetof(SelWs, br_coarse) : 0u;
-    hipLaunchKernelGGL(k_sel_clear, dim3((unsigned)(1024 / c < 8 ? 8 : 1024 / c), (unsigned)c), dim3(256), 0, st, b, a_end,
-                       b_begin, b_end);
-    MQ_HIP(hipGetLastError());
-    FinishArgs fin_last = {dtype, gamma, out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
-                           out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr};
-    if (bracket) {
-      int64_t nb = (m / 4 + 1024 * 8 - 1) / (1024 * 8);
-      int64_t cap = 256 / c < 2 ? 2 : 256 / c;
-      MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 SEL_TOP_BINS * 4));
-      hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(1024),
-                         SEL_TOP_BINS * 4, st, b);
-      hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)c), dim3(256), 0, st, b, (uint64_t)r_lo, (uint64_t)r_hi);
-      hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / c < 8 ? 8 : 512 / c), (unsigned)c), dim3(256), 0, st, b);
-      nb = (n / 4 + 256 * 8 - 1) / (256 * 8);
-      cap = 2048 / c < 16 ? 16 : 2048 / c;
-      hipLaunchKernelGGL(k_sel_bracket, dim3((unsigned)(nb > cap ? cap : nb), (unsigned)c), dim3(256), 0, st, b);
-      hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, (uint64_t)k0, (uint64_t)k1, fin_last);
-      MQ_HIP(hipGetLastError());
-    }
-    const int guard = bracket ? 1 : 0;  // the exact route returns at once for slices the bracket resolved
-    for (int level = 0; level <= levels; ++level) {
-      if ((rc = launch_accumulate(b, c, dtype, level, st, guard))) return rc;
-      FinishArgs fin = fin_last;
-      if (level != levels) fin.dtype = -1;
-      hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)c), dim3(256), 0, st, b, level, (uint64_t)k0, (uint64_t)k1, fin, guard);
-      MQ_HIP(hipGetLastError());
-    }
+    int rc = mq_percentile_multi(xs ? xs + done : nullptr, ns, c, dtype, pct,
+                                 out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
+                                 out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr, workspace,
+                                 workspace_bytes, hip_stream);
+    if (rc) return rc;
   }
   return MQ_OK;
 }

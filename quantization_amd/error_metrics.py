@@ -31,6 +31,9 @@ def _bind():
     L.mq_percentile_batch_workspace_bytes.argtypes = [i32]
     L.mq_percentile_batch.restype = ctypes.c_int
     L.mq_percentile_batch.argtypes = [ctypes.POINTER(vp), i32, i32, i64, ctypes.c_double, vp, vp, vp, sz, vp]
+    L.mq_percentile_multi.restype = ctypes.c_int
+    L.mq_percentile_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, ctypes.c_double, vp, vp, vp,
+                                      sz, vp]
     L.mq_error_workspace_bytes.restype = sz
     L.mq_error_workspace_bytes.argtypes = [i64, i64, i32]
     L.mq_error_stats.restype = ctypes.c_int
@@ -86,9 +89,41 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
     out = torch.empty(B, dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() + i * n * x.element_size() for i in range(B)])
     with torch.cuda.device(x.device):
-        ws, stream = workspace(x.device, L.mq_percentile_batch_workspace_bytes(min(B, 32)))
+        ws, stream = workspace(x.device, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
         st = L.mq_percentile_batch(ptrs, B, _DT[x.dtype], n, float(pct), out.data_ptr(), None, ws.data_ptr(),
                                    ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return out
+
+
+@torch.no_grad()
+def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0) -> torch.Tensor:
+    """np.percentile(x, pct) for each of a list of non-negative float32 / float64 device tensors of one dtype
+    (any lengths; each flattened, contiguous and 16-byte aligned): one set of launches per 64 arrays."""
+    if not xs:
+        raise ValueError("percentile_multi() needs at least one array")
+    dtype, dev = xs[0].dtype, xs[0].device
+    if dtype not in (torch.float32, torch.float64):
+        raise ValueError("percentile_multi() takes float32 or float64 tensors")
+    flat = []
+    for x in xs:
+        if x.dtype != dtype or x.device != dev or not x.is_cuda:
+            raise ValueError("percentile_multi(): one dtype, one ROCm device")
+        if x.numel() == 0:
+            raise IndexError("percentile of an empty array")
+        x = x.contiguous().reshape(-1)
+        if x.data_ptr() % 16:
+            x = x.clone()
+        flat.append(x)
+    B = len(flat)
+    L = _bind()
+    out = torch.empty(B, dtype=dtype, device=dev)
+    ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() for x in flat])
+    ns = (ctypes.c_int64 * B)(*[x.numel() for x in flat])
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
+        st = L.mq_percentile_multi(ptrs, ns, B, _DT[dtype], float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                   stream.cuda_stream)
     _lib.check(st)
     return out
 

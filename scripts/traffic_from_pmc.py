@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the quantize / select kernels from two rocprofv3 --pmc passes
+(FETCH_SIZE in one run, WRITE_SIZE in another; both counters are in KiB).
+
+    scripts/traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> [workload]
+
+gfx950 correction: FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the
+read side is doubled (checked here on torch's float32 multiply over the 1 GiB weight stack, whose read
+size is known); WRITE_SIZE is exact for 16-byte-per-lane stores.  Writes profiles/traffic.json."""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0][:60]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    workload = sys.argv[3] if len(sys.argv) > 3 else "c2"
+    rows = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not (k.startswith("void k_") or k.startswith("k_")):
+            continue
+        f = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [0])))
+        w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
+        rows[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+                   "hbm_bytes": 2 * f * 1024 + w * 1024}
+        print(f"{k:50s} n={rows[k]['launches']:4d} read {2*f*1024/1e6:10.1f} MB  write {w*1024/1e6:10.1f} MB")
+    quant = [v for k, v in rows.items() if "k_quant" in k]
+    per_launch = sum(v["hbm_bytes"] for v in quant) / max(1, len(quant))
+    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
+    data = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    data[workload] = round(per_launch)
+    data[workload + "_detail"] = rows
+    json.dump(data, open(out_path, "w"), indent=1)
+    print("fused quantize HBM bytes per launch:", round(per_launch))
+
+
+if __name__ == "__main__":
+    main()

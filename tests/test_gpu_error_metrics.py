@@ -193,3 +193,15 @@ def test_vector_mse_stats(em):
         vec = sse / L
         assert p99.cpu().numpy().tobytes() == np.array([np.percentile(v, 99) for v in vec]).tobytes(), L
         np.testing.assert_allclose(mean.cpu().numpy(), vec.mean(1), rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_percentile_multi_mixed_lengths(em, dtype):
+    """Arrays of different lengths in one call: small ones (exact route), large float32 ones (sample +
+    bracket route), more than 64 arrays (several groups)."""
+    rng = np.random.default_rng(31)
+    lens = [1, 7, 1000, 4096, (1 << 21) + 16, 100003, (1 << 22), 5, 3_000_000] + [2048 + 4 * i for i in range(70)]
+    arrs = [(np.abs(rng.standard_normal(n)) * rng.random()).astype(dtype) for n in lens]
+    got = em.percentile_multi([torch.from_numpy(a).cuda() for a in arrs], 99).cpu().numpy()
+    want = np.array([np.percentile(a, 99) for a in arrs], dtype)
+    assert got.tobytes() == want.tobytes()
