@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 import quantization_amd as qa  # noqa: E402
 from quantization_amd import _lib  # noqa: E402
 from quantization_amd.error_metrics import percentile_multi, vector_mse_stats  # noqa: E402
-from quantization_amd.fused import quantize_batch  # noqa: E402
+from quantization_amd.fused import QuantResult, quantize_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -101,39 +101,50 @@ class Workload:
         self.launches = len(self.batches)
         self.device = device
         self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
+        # per-tensor constants of the statistics step, resident on the device
+        lens, counts = [], []
+        for w, fmt, dt, gs, outs in self.batches:
+            L = gs if gs else w.shape[2]
+            lens += [L] * w.shape[0]
+            counts += [w.shape[1] * w.shape[2]] * w.shape[0]
+        self.pow2 = all(L & (L - 1) == 0 for L in lens)
+        self.vec_len = torch.tensor(lens, dtype=torch.float64, device=device)
+        self.numel = torch.tensor(counts, dtype=torch.float64, device=device)
+        self.totals = torch.zeros(self.tensors, 2, dtype=torch.float64, device=device)
 
     def step(self):
         """All fused quantize launches of the step, then ONE set of select launches per dtype for the P99s of
         every tensor of the step (the chains of short kernels run once per step, not once per batch)."""
-        results = []
+        results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
-            # one preallocated output set per batch: outputs cycle through > 256 MiB so they reach HBM
-            res = quantize_batch(w, fmt, 8, gs, dt, out=self.results.get(k), **outs)
+            # one preallocated output set per batch: outputs cycle through > 256 MiB so they reach HBM; the
+            # [sum err^2, sum |err|] pairs of all batches land in one table
+            res = self.results.get(k)
+            if res is None:
+                res = QuantResult(0, 0, 0)
+                res._bufs = {"totals": self.totals[row:row + w.shape[0]]}
+            # the exact P99 of |err| is selected inside the quantize pass (fed selection)
+            res = quantize_batch(w, fmt, 8, gs, dt, out=res, p99=99 if outs.get("abs_err") is not None else None, **outs)
+            assert res.totals.data_ptr() == self.totals[row].data_ptr()
             self.results[k] = res
             results.append(res)
-        rec, row = self.record, 0
-        vecs, lens, errs = [], [], []
-        for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
-            B, L = w.shape[0], (gs if gs else w.shape[2])
-            rec[row:row + B, 0:2] = res.totals                          # sum err^2, sum |err|
-            # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
-            rec[row:row + B, 2] = res.totals[:, 0] / (L * res.nseg)
-            vecs += [res.seg_sse[i] for i in range(B)]
-            lens += [L] * B
-            if res.abs_err is not None:
-                errs += [res.abs_err[i] for i in range(B)]
-            row += B
-        # exact P99 of every per-vector MSE list (float64 select); L is a power of two or the division is
-        # applied to the list first (vector_mse_stats does the latter per batch)
-        if all(L & (L - 1) == 0 for L in lens):
-            rec[:, 3] = percentile_multi(vecs, 99) / torch.tensor(lens, dtype=torch.float64, device=self.device)
+            row += w.shape[0]
+        rec = self.record
+        rec[:, 0:2] = self.totals
+        # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
+        rec[:, 2] = self.totals[:, 0] / self.numel
+        # exact P99 of every per-vector MSE list (float64 select).  A power-of-two L divides after the select
+        # (an exponent shift commutes with it); otherwise the list is divided first, per batch.
+        if self.pow2:
+            vecs = [res.seg_sse[i] for res in results for i in range(res.seg_sse.shape[0])]
+            rec[:, 3] = percentile_multi(vecs, 99) / self.vec_len
         else:
             row = 0
             for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
                 rec[row:row + w.shape[0], 3] = vector_mse_stats(res.seg_sse, gs if gs else w.shape[2], 99)[1]
                 row += w.shape[0]
-        if errs:
-            rec[:len(errs), 4] = percentile_multi(errs, 99)              # exact P99 of |err| (float32 select)
+        if results[0].abs_p99 is not None:
+            rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
         return [rec]
 
 

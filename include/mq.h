@@ -101,6 +101,19 @@ size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t rows, int64_t co
 int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
                       const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/*
+ * mq_quantize_batch plus p99[i] = np.percentile(abs_err_i, pct) (float32, method 'linear': the P99 of
+ * elwise_error/onnx_error_cli.py:113-114) for every tensor, with the selection fed from the quantize pass
+ * itself: a sampling pass over 1/32 of the weight brackets the wanted ranks, the full pass counts the errors
+ * below the bracket and histograms those inside it while they are in registers, so the error array is not
+ * read back (the two-pass selection over it runs only when the bracket misses).  Every item must request
+ * the float32 abs_err array (16-byte aligned).  p99: device array of `count` floats.
+ */
+size_t mq_quantize_p99_batch_workspace_bytes(int32_t count, int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
+int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
+                          const mq_quant_cfg* cfg, double pct, float* p99, void* workspace, size_t workspace_bytes,
+                          void* hip_stream);
+
 /* Bytes of device workspace mq_percentile needs (histograms + selection state). */
 size_t mq_percentile_workspace_bytes(void);
 

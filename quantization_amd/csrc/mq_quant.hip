@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "mq_common.h"
+#include "mq_sel.h"
 
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
 
@@ -53,7 +54,16 @@ struct QuantParams {
   double* seg_sse;
   double* partials;      // [gridDim.x][2]
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
+  int32_t sel_mode;      // SEL_FEED_*: feed the float32 |error| values to a percentile selection
+  SelWs* sel_ws;         // this tensor's selection workspace
 };
+
+// Per-lane accumulators threaded through the element routines.
+struct Acc {
+  double abs;   // sum of |error|
+  SelFeed sel;  // selection feed (off unless sel_mode)
+};
+extern __shared__ uint32_t sel_lds[];  // 2 * SEL_FEED_HASH words when sel_mode is on, else none
 
 // Up to MQ_MAX_BATCH same-shaped tensors per launch (blockIdx.y picks the tensor); the per-tensor
 // pointers travel in the kernel arguments, so a batch needs no descriptor upload.
@@ -71,6 +81,7 @@ struct BatchItem {
 struct QuantBatch {
   QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
   int64_t ws_stride;   // bytes between the tensors' workspace slices
+  char* sel_ws;        // selection workspace of tensor 0 (slices of sizeof(SelWs)), when common.sel_mode
   BatchItem item[MQ_MAX_BATCH];
 };
 static const size_t kWsHeader = 256;  // reduction words at the start of a tensor's workspace slice
@@ -83,6 +94,7 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
   char* ws = reinterpret_cast<char*>(const_cast<uint32_t*>(b.common.tred)) + (int64_t)blockIdx.y * b.ws_stride;
   p.tred = reinterpret_cast<const uint32_t*>(ws);
   p.partials = reinterpret_cast<double*>(ws + kWsHeader);
+  p.sel_ws = p.sel_mode ? reinterpret_cast<SelWs*>(b.sel_ws + (int64_t)blockIdx.y * sizeof(SelWs)) : nullptr;
   return p;
 }
 
@@ -374,9 +386,9 @@ __device__ __forceinline__ void error_sums(const float* e, double& sse, double& 
 //  * rint(x) for |x| < 512 is (x + 1536) - 1536 in float16 (ulp 1 in [1024, 2048), round to nearest even);
 //    the low byte of the float16 bits of 1536 + q (0x6600 + q) is q's two's-complement byte.
 //  * symmetric: |v / s| <= qmax * (1 + 2^-11) < qmax + 0.5, so the clamp to +-qmax never acts.
-template <int FMT>
+template <int FMT, bool SEL>
 __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
-                                              double& acc_abs) {
+                                              Acc& acc) {
   const uint32_t s2 = dup16(h_bits(sp.s)), zp2 = dup16(h_bits(sp.zp));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
   u32x4 dq, cw;
@@ -429,15 +441,16 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
   double sse = 0.0;
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0);
-    error_sums(e, sse, acc_abs);
+    error_sums(e, sse, acc.abs);
+    if constexpr (SEL) sel_feed8(acc.sel, e);
   }
   return sse;
 }
 
 // Slow path: the contract element by element (any float16 input, including inf / NaN / huge v / s).
-template <int FMT>
+template <int FMT, bool SEL>
 __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
-                                           double& acc_abs) {
+                                           Acc& acc) {
   const half_t qmax_h = (half_t)p.qmax;
   u32x4 dq, c16;
   uint32_t c8[2] = {0u, 0u};
@@ -485,22 +498,23 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
   double sse = 0.0;
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0);
-    error_sums(e, sse, acc_abs);
+    error_sums(e, sse, acc.abs);
+    if constexpr (SEL) sel_feed8(acc.sel, e);
   }
   return sse;
 }
 
-template <int FMT>
+template <int FMT, bool SEL>
 __device__ __forceinline__ double quant8(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
-                                         double& acc_abs) {
-  if (__builtin_expect(sp.slow, 0)) return quant8_slow<FMT>(p, raw, sp, e0, acc_abs);
-  return quant8_fast<FMT>(p, raw, sp, e0, acc_abs);
+                                         Acc& acc) {
+  if (__builtin_expect(sp.slow, 0)) return quant8_slow<FMT, SEL>(p, raw, sp, e0, acc);
+  return quant8_fast<FMT, SEL>(p, raw, sp, e0, acc);
 }
 
 // quant_datatype's per-tensor float32 branch (quant_weight.py:562-575): x = w32 / s in float32, table
 // lookup in float32, (q * s) rounded to float32 and then to float16.
 __device__ __forceinline__ double quant8_lut_f32(const QuantParams& p, const float* w32, u32x4 raw, float s,
-                                                 int64_t e0, double& acc_abs) {
+                                                 int64_t e0, Acc& acc) {
   u32x4 dq, c16;
   float e[8];
 #pragma unroll
@@ -518,7 +532,7 @@ __device__ __forceinline__ double quant8_lut_f32(const QuantParams& p, const flo
   double sse = 0.0;
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0);
-    error_sums(e, sse, acc_abs);
+    error_sums(e, sse, acc.abs);
   }
   return sse;
 }
@@ -543,17 +557,24 @@ __device__ __forceinline__ void block_partials(const QuantParams& p, double sse,
 // SC_SUBWAVE: a segment is T <= 64 lanes of one wave.  A wave streams NV x 1 KiB per iteration; the NV
 // vectors a lane holds belong to NV different segments.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int T, int NV>
+template <int FMT, int T, int NV, bool SEL>
 __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
-  double acc_sse = 0.0, acc_abs = 0.0;
+  double acc_sse = 0.0;
+  Acc acc;
+  acc.abs = 0.0;
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
   constexpr int SPW = 64 / T;  // segments per wave per vector slot
   const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t tiles = (p.nseg + (int64_t)SPW * NV - 1) / ((int64_t)SPW * NV);
+  // sampling pass of a selection: one pseudo-randomly chosen tile of every 32
+  const bool samp = SEL && p.sel_mode == SEL_FEED_SAMPLE;
+  const int64_t steps = samp ? tiles / 32 : tiles;
+  auto tile_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
   const bool lane_in_seg = tl < p.vecs_per_seg;
   // Software pipeline: the next tile's loads are issued before the current tile is computed, so a wave
   // keeps 2 x NV KiB in flight.
@@ -566,8 +587,9 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
                                             : u32x4{0, 0, 0, 0};
     }
   };
-  if (gw < tiles) issue(gw, nxt);
-  for (int64_t tile = gw; tile < tiles; tile += nwaves) {
+  if (gw < steps) issue(tile_of(gw), nxt);
+  for (int64_t t = gw; t < steps; t += nwaves) {
+    const int64_t tile = tile_of(t);
     u32x4 raw[NV];
     bool valid[NV];
     int64_t seg[NV];
@@ -577,7 +599,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
       seg[j] = (tile * NV + j) * SPW + team;
       valid[j] = lane_in_seg && seg[j] < p.nseg;
     }
-    if (tile + nwaves < tiles) issue(tile + nwaves, nxt);
+    if (t + nwaves < steps) issue(tile_of(t + nwaves), nxt);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       SegP sp;
@@ -592,7 +614,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
       }
       double s = 0.0;
       const int64_t e0 = seg[j] * p.L + (int64_t)tl * 8;
-      if (valid[j]) s = quant8<FMT>(p, raw[j], sp, e0, acc_abs);
+      if (valid[j]) s = quant8<FMT, SEL>(p, raw[j], sp, e0, acc);
       acc_sse += s;
       if (p.seg_sse) {
         s = team_sum<T>(s);
@@ -604,15 +626,16 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
       }
     }
   }
-  block_partials(p, acc_sse, acc_abs, lds);
+  block_partials(p, acc_sse, acc.abs, lds);
+  if constexpr (SEL) sel_feed_flush(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
 // SC_WAVE / SC_BLOCK: a segment (a row, or a long group) is held in the registers of one wave or one
 // workgroup, NV vectors per lane, interleaved so that every load instruction is 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int NV, bool BLOCK>
-__device__ __forceinline__ void row_body(const QuantParams& p, double* lds, double& acc_sse, double& acc_abs) {
+template <int FMT, int NV, bool BLOCK, bool SEL>
+__device__ __forceinline__ void row_body(const QuantParams& p, double* lds, double& acc_sse, Acc& acc) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t first = BLOCK ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * nw + wv;
   const int64_t stride = BLOCK ? (int64_t)gridDim.x : (int64_t)gridDim.x * nw;
@@ -630,10 +653,15 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
       dst[j] = v < p.vecs_per_seg ? load8_f16(p.w, p.in_dtype, sg * p.L + (int64_t)v * 8) : u32x4{0, 0, 0, 0};
     }
   };
+  // sampling pass of a selection: one pseudo-randomly chosen segment of every 32
+  const bool samp = SEL && p.sel_mode == SEL_FEED_SAMPLE;
+  const int64_t steps = samp ? p.nseg / 32 : p.nseg;
+  auto seg_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
   if constexpr (PREFETCH) {
-    if (first < p.nseg) issue(first, nxt);
+    if (first < steps) issue(seg_of(first), nxt);
   }
-  for (int64_t seg = first; seg < p.nseg; seg += stride) {
+  for (int64_t t = first; t < steps; t += stride) {
+    const int64_t seg = seg_of(t);
     const int64_t base = seg * p.L;
     u32x4 raw[NV];
     bool valid[NV];
@@ -642,7 +670,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
     if constexpr (PREFETCH) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) raw[j] = nxt[j];
-      if (seg + stride < p.nseg) issue(seg + stride, nxt);
+      if (t + stride < steps) issue(seg_of(t + stride), nxt);
     } else {
       issue(seg, raw);
     }
@@ -677,7 +705,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
-      if (valid[j]) s += quant8<FMT>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc_abs);
+      if (valid[j]) s += quant8<FMT, SEL>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc);
     acc_sse += s;
     if (p.seg_sse) {
       s = wave_sum(s);
@@ -702,22 +730,30 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
   }
 }
 
-template <int FMT, int NV>
+template <int FMT, int NV, bool SEL>
 __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
-  double acc_sse = 0.0, acc_abs = 0.0;
-  row_body<FMT, NV, false>(p, lds, acc_sse, acc_abs);
-  block_partials(p, acc_sse, acc_abs, lds);
+  double acc_sse = 0.0;
+  Acc acc;
+  acc.abs = 0.0;
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
+  row_body<FMT, NV, false, SEL>(p, lds, acc_sse, acc);
+  block_partials(p, acc_sse, acc.abs, lds);
+  if constexpr (SEL) sel_feed_flush(acc.sel);
 }
 
-template <int FMT, int NV, int THREADS>
+template <int FMT, int NV, int THREADS, bool SEL>
 __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[96];
-  double acc_sse = 0.0, acc_abs = 0.0;
-  row_body<FMT, NV, true>(p, lds, acc_sse, acc_abs);
-  block_partials(p, acc_sse, acc_abs, lds);
+  double acc_sse = 0.0;
+  Acc acc;
+  acc.abs = 0.0;
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
+  row_body<FMT, NV, true, SEL>(p, lds, acc_sse, acc);
+  block_partials(p, acc_sse, acc.abs, lds);
+  if constexpr (SEL) sel_feed_flush(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,7 +807,9 @@ template <int FMT, int NV>
 __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
-  double acc_sse = 0.0, acc_abs = 0.0;
+  double acc_sse = 0.0;
+  Acc acc;  // (this scope never feeds a selection)
+  acc.abs = 0.0;
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -809,9 +847,9 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
       if (FMT == MQ_LUT_FP && p.f32_math) {
         float w32[8];
         load8_f32(p.w, p.in_dtype, e0, w32);
-        acc_sse += quant8_lut_f32(p, w32, raw[j], s32, e0, acc_abs);
+        acc_sse += quant8_lut_f32(p, w32, raw[j], s32, e0, acc);
       } else {
-        acc_sse += quant8<FMT>(p, raw[j], sp, e0, acc_abs);
+        acc_sse += quant8<FMT, false>(p, raw[j], sp, e0, acc);
       }
     }
   }
@@ -819,7 +857,7 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
     if (p.scale) p.scale[0] = (uint16_t)h_bits(sp.s);
     if (FMT == MQ_INT_ASYM && p.zp) p.zp[0] = (uint16_t)h_bits(sp.zp);
   }
-  block_partials(p, acc_sse, acc_abs, lds);
+  block_partials(p, acc_sse, acc.abs, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -989,42 +1027,43 @@ static bool recip_ok_cached(float c) {
   return ok;
 }
 
-template <int FMT, int NV>
-static void launch_team(int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
+template <int FMT, int NV, bool SEL>
+static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
   switch (team_log2) {
-    case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV>), grid, dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((k_quant_team<FMT, 2, NV>), grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((k_quant_team<FMT, 4, NV>), grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((k_quant_team<FMT, 8, NV>), grid, dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((k_quant_team<FMT, 16, NV>), grid, dim3(256), 0, st, p); break;
-    case 5: hipLaunchKernelGGL((k_quant_team<FMT, 32, NV>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((k_quant_team<FMT, 64, NV>), grid, dim3(256), 0, st, p); break;
+    case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    case 1: hipLaunchKernelGGL((k_quant_team<FMT, 2, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    case 2: hipLaunchKernelGGL((k_quant_team<FMT, 4, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    case 3: hipLaunchKernelGGL((k_quant_team<FMT, 8, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    case 4: hipLaunchKernelGGL((k_quant_team<FMT, 16, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    case 5: hipLaunchKernelGGL((k_quant_team<FMT, 32, NV, SEL>), grid, dim3(256), lds, st, p); break;
+    default: hipLaunchKernelGGL((k_quant_team<FMT, 64, NV, SEL>), grid, dim3(256), lds, st, p); break;
   }
 }
 
-template <int FMT>
-static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
+// SEL: the variants that feed a percentile selection (team / wave / workgroup scopes only).
+template <int FMT, bool SEL>
+static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
+                       const QuantBatch& p) {
   if (scope == SC_SUBWAVE) {
-    launch_team<FMT, 4>(team_log2, grid, st, p);
-  } else if (scope == SC_TENSOR) {
-    hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
+    launch_team<FMT, 4, SEL>(team_log2, grid, lds, st, p);
   } else if (scope == SC_WAVE) {
     switch (nv) {
-      case 2: hipLaunchKernelGGL((k_quant_wave<FMT, 2>), grid, dim3(256), 0, st, p); break;
-      case 4: hipLaunchKernelGGL((k_quant_wave<FMT, 4>), grid, dim3(256), 0, st, p); break;
-      case 8: hipLaunchKernelGGL((k_quant_wave<FMT, 8>), grid, dim3(256), 0, st, p); break;
-      default: hipLaunchKernelGGL((k_quant_wave<FMT, 16>), grid, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_quant_wave<FMT, 2, SEL>), grid, dim3(256), lds, st, p); break;
+      case 4: hipLaunchKernelGGL((k_quant_wave<FMT, 4, SEL>), grid, dim3(256), lds, st, p); break;
+      case 8: hipLaunchKernelGGL((k_quant_wave<FMT, 8, SEL>), grid, dim3(256), lds, st, p); break;
+      default: hipLaunchKernelGGL((k_quant_wave<FMT, 16, SEL>), grid, dim3(256), lds, st, p); break;
     }
   } else if (scope == SC_BLOCK) {
     if (threads == 256) {
-      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 256>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 256>), grid, dim3(256), 0, st, p);
+      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 256, SEL>), grid, dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 256, SEL>), grid, dim3(256), lds, st, p);
     } else {
-      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 1024>), grid, dim3(1024), 0, st, p);
-      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 1024>), grid, dim3(1024), 0, st, p);
+      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 1024, SEL>), grid, dim3(1024), lds, st, p);
+      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 1024, SEL>), grid, dim3(1024), lds, st, p);
     }
-  } else {
-    hipLaunchKernelGGL((k_quant_generic<FMT>), grid, dim3(256), 0, st, p);
+  } else if constexpr (!SEL) {
+    if (scope == SC_TENSOR) hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_quant_generic<FMT>), grid, dim3(256), 0, st, p);
   }
 }
 
@@ -1051,8 +1090,13 @@ extern "C" size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t, int6
 static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; }
 
 // One launch (plus one finalize launch when totals are requested) for up to MQ_MAX_BATCH tensors.
+// sel_mode: SEL_FEED_OFF, or one of the two passes of a fed selection (SEL_FEED_SAMPLE launches the kernels
+// over the sampled tiles / rows only, with every output suppressed).  With `sampled` set nothing is launched:
+// it receives the number of elements per tensor the sampling pass would feed (0: this shape's kernels cannot
+// feed a selection).
 static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
-                           const mq_quant_cfg* cfg, void* workspace, hipStream_t st) {
+                           const mq_quant_cfg* cfg, void* workspace, hipStream_t st, int sel_mode = SEL_FEED_OFF,
+                           char* sel_ws = nullptr, int64_t* sampled = nullptr) {
   const int64_t n = rows * cols;
   QuantBatch b = {};
   QuantParams& p = b.common;
@@ -1097,6 +1141,16 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     it.seg_sse = o.seg_sse;
     it.totals = o.totals;
   }
+  p.sel_mode = sel_mode;
+  b.sel_ws = sel_ws;
+  if (sel_mode == SEL_FEED_SAMPLE) {  // errors only
+    for (int i = 0; i < count; ++i) {
+      BatchItem& it = b.item[i];
+      it.deq = nullptr; it.codes = nullptr; it.scale = nullptr; it.zp = nullptr; it.abs_err = nullptr;
+      it.seg_sse = nullptr; it.totals = nullptr;
+    }
+    p.need_err = 1;
+  }
   // flags the kernels test through the (per-tensor) pointers: keep the common copy non-null where set
   p.deq = b.item[0].deq; p.codes = b.item[0].codes; p.scale = b.item[0].scale; p.zp = b.item[0].zp;
   p.abs_err = b.item[0].abs_err; p.seg_sse = b.item[0].seg_sse;
@@ -1132,6 +1186,24 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   if (count > 1 && max_grid > 64) max_grid = max_grid / count < 64 ? 64 : max_grid / count;
   dim3 grid((unsigned)(work_blocks < max_grid ? work_blocks : max_grid), (unsigned)count);
 
+  if (sampled) {
+    *sampled = 0;
+    if (scope == SC_SUBWAVE) {  // tiles of (64 / team) * 4 segments, one of every 32 tiles
+      const int64_t per_tile = (int64_t)(64 >> team_log2) * 4;
+      const int64_t tiles = (p.nseg + per_tile - 1) / per_tile;
+      for (int64_t t = 0; t < tiles / 32; ++t) {
+        const int64_t first = (t * 32 + (int64_t)sample_line((uint32_t)t)) * per_tile;
+        const int64_t segs = p.nseg - first < per_tile ? p.nseg - first : per_tile;
+        *sampled += segs * p.L;
+      }
+    } else if (scope == SC_WAVE || scope == SC_BLOCK) {  // one of every 32 segments
+      *sampled = (p.nseg / 32) * p.L;
+    }
+    return MQ_OK;
+  }
+  if (sel_mode != SEL_FEED_OFF && scope != SC_SUBWAVE && scope != SC_WAVE && scope != SC_BLOCK) return MQ_ERR_UNSUPPORTED;
+  const size_t lds = sel_mode != SEL_FEED_OFF ? (size_t)2 * SEL_FEED_HASH * sizeof(uint32_t) : 0;
+
   if (scope == SC_TENSOR) {
     for (int i = 0; i < count; ++i)
       MQ_HIP(hipMemsetAsync(static_cast<char*>(workspace) + (size_t)i * ws_slice_bytes(), 0, 16, st));
@@ -1140,12 +1212,21 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < cap ? rb : cap), (unsigned)count), dim3(256), 0, st, b);
   }
   switch (cfg->format) {
-    case MQ_INT_SYM: launch_fmt<MQ_INT_SYM>(scope, nv, threads, team_log2, grid, st, b); break;
-    case MQ_INT_ASYM: launch_fmt<MQ_INT_ASYM>(scope, nv, threads, team_log2, grid, st, b); break;
-    default: launch_fmt<MQ_LUT_FP>(scope, nv, threads, team_log2, grid, st, b); break;
+    case MQ_INT_SYM:
+      if (sel_mode) launch_fmt<MQ_INT_SYM, true>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_INT_SYM, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      break;
+    case MQ_INT_ASYM:
+      if (sel_mode) launch_fmt<MQ_INT_ASYM, true>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_INT_ASYM, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      break;
+    default:
+      if (sel_mode) launch_fmt<MQ_LUT_FP, true>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_LUT_FP, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      break;
   }
   MQ_HIP(hipGetLastError());
-  if (o0.totals || (scope == SC_TENSOR && o0.seg_sse)) {
+  if (sel_mode != SEL_FEED_SAMPLE && (o0.totals || (scope == SC_TENSOR && o0.seg_sse))) {
     hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, st, b, (int)grid.x,
                        scope == SC_TENSOR ? 1 : 0);
     MQ_HIP(hipGetLastError());
@@ -1181,4 +1262,61 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
   if (!out) return MQ_ERR_ARG;
   mq_quant_item item = {w, *out};
   return mq_quantize_batch(&item, 1, w_dtype, rows, cols, cfg, workspace, workspace_bytes, hip_stream);
+}
+
+// ---- quantize + exact percentile of the float32 |error| in the same pass ---------------------------------
+static size_t sel_slices_offset(int32_t count) {
+  return ((size_t)(count > MQ_MAX_BATCH ? MQ_MAX_BATCH : (count < 1 ? 1 : count)) * ws_slice_bytes() + 255) / 256 * 256;
+}
+extern "C" size_t mq_quantize_p99_batch_workspace_bytes(int32_t count, int64_t, int64_t, const mq_quant_cfg*) {
+  const int32_t c = count > MQ_MAX_BATCH ? MQ_MAX_BATCH : (count < 1 ? 1 : count);
+  return sel_slices_offset(count) + (size_t)c * sel_ws_bytes();
+}
+
+extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows,
+                                     int64_t cols, const mq_quant_cfg* cfg, double pct, float* p99,
+                                     void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (!cfg || count < 0 || rows < 0 || cols < 0 || (count > 0 && !items) || !p99) return MQ_ERR_ARG;
+  if (!(pct >= 0.0 && pct <= 100.0)) return MQ_ERR_ARG;
+  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && cfg->format != MQ_LUT_FP) return MQ_ERR_ARG;
+  if (cfg->format != MQ_LUT_FP && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math && !(cfg->format == MQ_LUT_FP && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
+  const int64_t n = rows * cols;
+  if (count == 0) return MQ_OK;
+  if (n == 0) return MQ_ERR_ARG;  // no percentile of an empty array
+  for (int32_t i = 0; i < count; ++i) {
+    // the stored float32 |error| array is what the exact two-pass route reads when the bracket misses
+    if (!items[i].w || !items[i].out.abs_err || items[i].out.abs_err_dtype != MQ_F32) return MQ_ERR_ARG;
+    if (!aligned(items[i].out.abs_err, 16)) return MQ_ERR_ALIGN;
+  }
+  if (!workspace || workspace_bytes < mq_quantize_p99_batch_workspace_bytes(count, rows, cols, cfg)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 16)) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  char* sel = static_cast<char*>(workspace) + sel_slices_offset(count);
+  for (int32_t done = 0; done < count; done += MQ_MAX_BATCH) {
+    const int32_t c = count - done < MQ_MAX_BATCH ? count - done : MQ_MAX_BATCH;
+    const mq_quant_item* it = items + done;
+    int64_t m = 0;
+    int rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_OFF, nullptr, &m);
+    if (rc) return rc;
+    const void* errs[MQ_MAX_BATCH];
+    for (int i = 0; i < c; ++i) errs[i] = it[i].out.abs_err;
+    if (m > 0 && sel_feed_eligible(n, m, pct)) {
+      if ((rc = sel_feed_begin(sel, c, st))) return rc;
+      if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_SAMPLE, sel))) return rc;
+      if ((rc = sel_feed_bracket(sel, c, n, m, pct, st))) return rc;
+      if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_COUNT, sel))) return rc;
+      if ((rc = sel_feed_finish(sel, c, errs, n, pct, p99 + done, st))) return rc;
+    } else {  // small tensors, quantiles at the very ends, per-tensor or unaligned shapes: select from the dump
+      if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st))) return rc;
+      int64_t ns[MQ_MAX_BATCH];
+      for (int i = 0; i < c; ++i) ns[i] = n;
+      if ((rc = mq_percentile_multi(errs, ns, c, MQ_F32, pct, p99 + done, nullptr, sel, (size_t)c * sel_ws_bytes(),
+                                    hip_stream)))
+        return rc;
+    }
+  }
+  return MQ_OK;
 }

@@ -31,45 +31,7 @@
 //            otherwise the slice's `ok` flag stays 0 and the exact level-0/level-1 kernels, which are
 //            always enqueued behind and return at once when `ok` is set, produce the result.
 // The bracket is only ever a guess about where to look: the counts that decide are exact.
-#include "mq_common.h"
-
-#define SEL_TOP_BINS 32768
-#define SEL_DIGIT_BINS 65536
-#define SEL_HASH 2048
-#define SEL_MAX_BATCH 64
-
-struct SelState {
-  uint64_t prefix[2];  // resolved high bits of the two keys, left-aligned in 63 bits
-  uint64_t rank[2];    // remaining rank inside the current prefix
-  int32_t same;        // 1 while both ranks share one prefix
-  int32_t pad;
-};
-
-struct SelLevel {  // histograms of one level >= 1, for the two tracked ranks
-  uint32_t coarse[2][SEL_DIGIT_BINS / 256];
-  uint32_t fine[2][SEL_DIGIT_BINS];
-};
-
-#define SEL_BR_BINS 16       // widest bracket, in level-0 bins
-#define SEL_BR_HASH 4096
-#define SEL_CHUNK_LINES 32   // one 256-byte line of every 32 is sampled
-#define SEL_BR_MIN_N (1 << 21)
-
-struct SelWs {
-  SelState st;
-  uint32_t br_lo, br_nb;     // bracket: first level-0 bin, number of bins (0: none)
-  uint32_t ok, pad0;         // 1: the bracket pass produced the result
-  unsigned long long below;  // exact number of elements under the bracket
-  uint32_t pad[48];
-  uint32_t top_coarse[SEL_TOP_BINS / 256];
-  uint32_t top[SEL_TOP_BINS];
-  SelLevel lvl[3];  // cleared once per selection, only as many as the dtype needs
-  uint32_t samp_coarse[SEL_TOP_BINS / 256];
-  uint32_t samp[SEL_TOP_BINS];
-  uint32_t br_coarse[SEL_BR_BINS * 256];
-  uint32_t br_fine[SEL_BR_BINS * 65536];
-};
-static_assert(offsetof(SelWs, top_coarse) == 256, "header is 256 bytes");
+#include "mq_sel.h"
 
 struct SelBatch {
   const void* x[SEL_MAX_BATCH];
@@ -309,9 +271,6 @@ __global__ __launch_bounds__(256) void k_sel_clear(const SelBatch b, uint32_t a_
   for (uint32_t i = nb0 + blockIdx.x * blockDim.x + threadIdx.x; i < nb1; i += gridDim.x * blockDim.x) base[i] = z;
 }
 
-// Which 256-byte line of 8 KiB chunk c is sampled.
-__device__ __forceinline__ uint32_t sample_line(uint32_t c) { return (c * 0x9E3779B1u) >> 27; }
-
 __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
   extern __shared__ uint32_t lh[];
   const u32x4* x = static_cast<const u32x4*>(b.x[blockIdx.y]);
@@ -540,15 +499,18 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) =
 
 // Sample ranks 8 standard deviations either side of the wanted quantile among the m sampled elements of an
 // array of n; false when the array is too small or the quantile too near an end for the bracket route.
-static bool bracket_ranks(int64_t n, int64_t k0, int64_t k1, int64_t* m_out, double* r_lo, double* r_hi) {
-  if (n < SEL_BR_MIN_N) return false;
-  const int64_t m = n / (SEL_CHUNK_LINES * 64) * 64;
+static bool bracket_ranks_m(int64_t n, int64_t m, int64_t k0, int64_t k1, double* r_lo, double* r_hi) {
+  if (n < SEL_BR_MIN_N || m < 1) return false;
   const double frac = (double)m / (double)n, p = ((double)k0 + 0.5) / (double)n;
   const double margin = 8.0 * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
   *r_lo = __builtin_floor((double)k0 * frac) - margin;
   *r_hi = __builtin_ceil((double)k1 * frac) + margin;
-  *m_out = m;
   return *r_lo >= 0.0 && *r_hi <= (double)(m - 1);
+}
+// ... with the sample k_sel_sample takes from a stored array
+static bool bracket_ranks(int64_t n, int64_t k0, int64_t k1, int64_t* m_out, double* r_lo, double* r_hi) {
+  *m_out = n / (SEL_CHUNK_LINES * 64) * 64;
+  return bracket_ranks_m(n, *m_out, k0, k1, r_lo, r_hi);
 }
 
 static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t dtype, int level, hipStream_t st,
@@ -750,4 +712,79 @@ extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct
   if (!x) return MQ_ERR_ARG;
   const void* xs[1] = {x};
   return mq_percentile_batch(xs, 1, dtype, n, pct, out, out_pair, workspace, workspace_bytes, hip_stream);
+}
+
+// ---- selection fed by another kernel (see mq_sel.h) ------------------------------------------------------
+size_t sel_ws_bytes() { return sizeof(SelWs); }
+
+bool sel_feed_eligible(int64_t n, int64_t m, double pct) {
+  int64_t k0, k1;
+  double g, lo, hi;
+  if (mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &g)) return false;
+  return bracket_ranks_m(n, m, k0, k1, &lo, &hi);
+}
+
+static void feed_batch(void* ws, int count, const void* const* xs, int64_t n, SelBatch* b) {
+  *b = SelBatch{};
+  for (int i = 0; i < count; ++i) {
+    b->x[i] = xs ? xs[i] : nullptr;
+    b->n[i] = n;
+  }
+  b->ws = static_cast<char*>(ws);
+  b->ws_stride = (int64_t)sizeof(SelWs);
+}
+
+int sel_feed_begin(void* ws, int count, hipStream_t st) {
+  SelBatch b;
+  feed_batch(ws, count, nullptr, 0, &b);
+  hipLaunchKernelGGL(k_sel_clear, dim3((unsigned)(1024 / count < 8 ? 8 : 1024 / count), (unsigned)count), dim3(256), 0, st,
+                     b, (uint32_t)ws_used_bytes(MQ_F32), (uint32_t)offsetof(SelWs, samp_coarse),
+                     (uint32_t)offsetof(SelWs, br_coarse));
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+int sel_feed_bracket(void* ws, int count, int64_t n, int64_t m, double pct, hipStream_t st) {
+  int64_t k0, k1;
+  double g, lo, hi;
+  int rc = mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &g);
+  if (rc) return rc;
+  if (!bracket_ranks_m(n, m, k0, k1, &lo, &hi)) return MQ_ERR_ARG;
+  SelBatch b;
+  feed_batch(ws, count, nullptr, n, &b);
+  SelSampleRanks sr = {};
+  for (int i = 0; i < count; ++i) {
+    sr.lo[i] = (uint64_t)lo;
+    sr.hi[i] = (uint64_t)hi;
+  }
+  hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)count), dim3(256), 0, st, b, sr);
+  hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / count < 8 ? 8 : 512 / count), (unsigned)count), dim3(256),
+                     0, st, b);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st) {
+  SelBatch b;
+  feed_batch(ws, count, xs, n, &b);
+  SelRanks rk = {};
+  for (int i = 0; i < count; ++i) {
+    int64_t k0, k1;
+    int rc = mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &rk.gamma[i]);
+    if (rc) return rc;
+    rk.k0[i] = (uint64_t)k0;
+    rk.k1[i] = (uint64_t)k1;
+  }
+  FinishArgs fin_last = {MQ_F32, static_cast<char*>(out), nullptr};
+  hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)count), dim3(256), 0, st, b, rk, fin_last);
+  MQ_HIP(hipGetLastError());
+  for (int level = 0; level <= 1; ++level) {  // the exact route, skipped per slice when the bracket held
+    int rc = launch_accumulate(b, count, n, MQ_F32, level, st, 1);
+    if (rc) return rc;
+    FinishArgs fin = fin_last;
+    if (level != 1) fin.dtype = -1;
+    hipLaunchKernelGGL(k_sel_scan, dim3((unsigned)count), dim3(256), 0, st, b, level, rk, fin, 1);
+    MQ_HIP(hipGetLastError());
+  }
+  return MQ_OK;
 }

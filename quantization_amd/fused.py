@@ -31,6 +31,7 @@ class QuantResult:
     abs_err: Optional[torch.Tensor] = None  # float32 or float16 [rows, cols]
     seg_sse: Optional[torch.Tensor] = None  # float64 [nseg]
     totals: Optional[torch.Tensor] = None   # float64 [2]: sum err^2, sum |err|
+    abs_p99: Optional[torch.Tensor] = None  # float32 [B]: percentile of the float32 |error| (quantize_batch(p99=))
 
 
 def require_device(t: torch.Tensor) -> torch.Tensor:
@@ -132,9 +133,14 @@ class _QuantItem(ctypes.Structure):
 @torch.no_grad()
 def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
                    f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, totals=False,
-                   out: Optional[QuantResult] = None) -> QuantResult:
+                   p99: Optional[float] = None, out: Optional[QuantResult] = None) -> QuantResult:
     """quantize() for a stack of same-shaped weights w[B, rows, cols] (e.g. one projection of every layer):
-    one fused launch per 32 tensors.  Every field of the result has a leading batch dimension."""
+    one fused launch per 32 tensors.  Every field of the result has a leading batch dimension.
+
+    p99: a percentile (e.g. 99) of each tensor's float32 |error| array, selected exactly while the errors
+    are produced (result.abs_p99, float32 [B]); needs abs_err=torch.float32."""
+    if p99 is not None and abs_err != torch.float32:
+        raise ValueError("p99 needs the float32 abs_err output")
     if w.dim() != 3:
         raise ValueError("quantize_batch() expects [B, rows, cols]")
     if w.dtype not in _DTYPES:
@@ -177,6 +183,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     b_abs = buf("abs_err", abs_err is not None, (B, rows, cols), abs_err or torch.float32)
     b_sse = buf("seg_sse", seg_sse, (B, nseg_pad), torch.float64)
     b_tot = buf("totals", totals, (B, 2), torch.float64)
+    res.abs_p99 = buf("abs_p99", p99 is not None, (B,), torch.float32)
     res._bufs = bufs
     res.deq, res.codes, res.abs_err, res.totals = b_deq, b_codes, b_abs, b_tot
     res.scale = None if b_scale is None else b_scale[:, :nseg]
@@ -206,10 +213,21 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
         L_.mq_quantize_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_void_p,
                                          ctypes.c_size_t, ctypes.c_void_p]
+        L_.mq_quantize_p99_batch_workspace_bytes.restype = ctypes.c_size_t
+        L_.mq_quantize_p99_batch_workspace_bytes.argtypes = L_.mq_quantize_batch_workspace_bytes.argtypes
+        L_.mq_quantize_p99_batch.restype = ctypes.c_int
+        L_.mq_quantize_p99_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         L_._batch_bound = True
     with torch.cuda.device(dev):
-        ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
-        st = L_.mq_quantize_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(), ws.numel(),
-                                  stream.cuda_stream)
+        if p99 is not None:
+            ws, stream = workspace(dev, L_.mq_quantize_p99_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
+            st = L_.mq_quantize_p99_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), float(p99),
+                                          res.abs_p99.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+        else:
+            ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
+            st = L_.mq_quantize_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
+                                      ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return res

@@ -272,3 +272,56 @@ def test_batched_launch_equals_single(qa):
                     assert torch.equal(rb.zero_point[i].view(torch.int16), r1.zero_point.view(torch.int16))
                 assert torch.equal(rb.abs_err[i], r1.abs_err)
                 assert torch.equal(rb.seg_sse[i], r1.seg_sse) and torch.equal(rb.totals[i], r1.totals)
+
+
+def test_fused_p99_matches_numpy_on_the_dump():
+    """quantize_batch(p99=): the percentile selected inside the quantize pass equals np.percentile of the
+    float32 |error| dump bit for bit, on shapes that take the fed route (team / wave / workgroup kernels,
+    >= 2^21 elements), on shapes that fall back to selecting from the dump, and all other outputs are
+    unchanged by it."""
+    import numpy as np
+    import torch
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize_batch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cases = [((2, 2048, 2048), _lib.INT_ASYM, None, 32), ((3, 1024, 4096), _lib.INT_SYM, None, 128),
+             ((2, 2048, 2048), _lib.LUT_FP, "fp8_e4m3", None), ((1, 256, 16384), _lib.INT_ASYM, None, None),
+             ((2, 2048, 1536), _lib.INT_ASYM, None, 96), ((2, 64, 1024), _lib.INT_SYM, None, 64),
+             ((1, 1024, 4096), _lib.INT_ASYM, None, -1)]
+    for shape, fmt, dt, gs in cases:
+        w = (torch.randn(*shape, generator=g, device="cuda") * 0.02).half()
+        for pct in (99, 50, 99.9):
+            a = quantize_batch(w, fmt, 8, gs, dt, abs_err=torch.float32, seg_sse=True, totals=True, p99=pct)
+            b = quantize_batch(w, fmt, 8, gs, dt, abs_err=torch.float32, seg_sse=True, totals=True)
+            for f in ("deq", "codes", "scale", "zero_point", "abs_err", "seg_sse", "totals"):
+                x, y = getattr(a, f), getattr(b, f)
+                assert (x is None) == (y is None)
+                if x is not None:
+                    assert torch.equal(x.view(torch.uint8), y.view(torch.uint8)), (shape, gs, f)
+            err = a.abs_err.cpu().numpy()
+            want = np.array([np.percentile(err[i].ravel(), pct) for i in range(shape[0])], np.float32)
+            assert a.abs_p99.cpu().numpy().tobytes() == want.tobytes(), (shape, fmt, gs, pct)
+
+
+def test_fused_p99_survives_a_misleading_sample():
+    """The sampling pass looks at one tile of every 32 (team kernels: (64 / team) * 4 segments per tile, tile
+    t * 32 + top 5 bits of t * 0x9E3779B1).  Zero weights in exactly those tiles make the sample say 'all
+    errors are 0'; the result must still be numpy's."""
+    import numpy as np
+    import torch
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize_batch
+    g = torch.Generator(device="cuda").manual_seed(6)
+    rows, cols, gs = 2048, 2048, 64          # team of 8 lanes: 8 segments x 4 = 32 segments per tile
+    w = (torch.randn(1, rows, cols, generator=g, device="cuda") * 0.02).half()
+    seg_per_tile = (64 // (gs // 8)) * 4
+    nseg = rows * cols // gs
+    tiles = (nseg + seg_per_tile - 1) // seg_per_tile
+    t = np.arange(tiles // 32, dtype=np.uint64)
+    tile = t * np.uint64(32) + (((t * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(27))
+    flat = w.view(-1, seg_per_tile * gs)
+    flat[torch.from_numpy(tile.astype(np.int64)).cuda()] = 0
+    a = quantize_batch(w, _lib.INT_ASYM, 8, gs, None, abs_err=torch.float32, p99=99)
+    want = np.float32(np.percentile(a.abs_err.cpu().numpy().ravel(), 99))
+    assert a.abs_p99.cpu().numpy().tobytes() == np.array([want], np.float32).tobytes()
+    assert want > 0
