@@ -56,6 +56,7 @@ struct QuantParams {
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
   int32_t sel_mode;      // SEL_FEED_*: feed the float32 |error| values to a percentile selection
   SelWs* sel_ws;         // this tensor's selection workspace
+  uint16_t* sel_samples; // sampling pass: this tensor's dense sample array
 };
 
 // Per-lane accumulators threaded through the element routines.
@@ -82,6 +83,7 @@ struct QuantBatch {
   QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
   int64_t ws_stride;   // bytes between the tensors' workspace slices
   char* sel_ws;        // selection workspace of tensor 0 (slices of sizeof(SelWs)), when common.sel_mode
+  int64_t sample_stride;  // uint16 elements between the tensors' sample arrays (common.sel_samples: tensor 0)
   BatchItem item[MQ_MAX_BATCH];
 };
 static const size_t kWsHeader = 256;  // reduction words at the start of a tensor's workspace slice
@@ -95,6 +97,7 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
   p.tred = reinterpret_cast<const uint32_t*>(ws);
   p.partials = reinterpret_cast<double*>(ws + kWsHeader);
   p.sel_ws = p.sel_mode ? reinterpret_cast<SelWs*>(b.sel_ws + (int64_t)blockIdx.y * sizeof(SelWs)) : nullptr;
+  p.sel_samples = p.sel_mode ? b.common.sel_samples + (int64_t)blockIdx.y * b.sample_stride : nullptr;
   return p;
 }
 
@@ -442,7 +445,7 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0);
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL) sel_feed8(acc.sel, e);
+    if constexpr (SEL) sel_feed8(acc.sel, e, e0);
   }
   return sse;
 }
@@ -499,7 +502,7 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0);
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL) sel_feed8(acc.sel, e);
+    if constexpr (SEL) sel_feed8(acc.sel, e, e0);
   }
   return sse;
 }
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   double acc_sse = 0.0;
   Acc acc;
   acc.abs = 0.0;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
   constexpr int SPW = 64 / T;  // segments per wave per vector slot
@@ -572,8 +575,9 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t tiles = (p.nseg + (int64_t)SPW * NV - 1) / ((int64_t)SPW * NV);
   // sampling pass of a selection: one pseudo-randomly chosen tile of every 32
+  // (of the FULL tiles, so that the samples are dense: tile t of the sample holds SPW * NV whole segments)
   const bool samp = SEL && p.sel_mode == SEL_FEED_SAMPLE;
-  const int64_t steps = samp ? tiles / 32 : tiles;
+  const int64_t steps = samp ? (p.nseg / ((int64_t)SPW * NV)) / 32 : tiles;
   auto tile_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
   const bool lane_in_seg = tl < p.vecs_per_seg;
   // Software pipeline: the next tile's loads are issued before the current tile is computed, so a wave
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   if (gw < steps) issue(tile_of(gw), nxt);
   for (int64_t t = gw; t < steps; t += nwaves) {
     const int64_t tile = tile_of(t);
+    if constexpr (SEL) acc.sel.sample_shift = (t - tile) * ((int64_t)SPW * NV) * p.L;
     u32x4 raw[NV];
     bool valid[NV];
     int64_t seg[NV];
@@ -663,6 +668,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
   for (int64_t t = first; t < steps; t += stride) {
     const int64_t seg = seg_of(t);
     const int64_t base = seg * p.L;
+    if constexpr (SEL) acc.sel.sample_shift = (t - seg) * p.L;
     u32x4 raw[NV];
     bool valid[NV];
 #pragma unroll
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   double acc_sse = 0.0;
   Acc acc;
   acc.abs = 0.0;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, false, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
   if constexpr (SEL) sel_feed_flush(acc.sel);
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   double acc_sse = 0.0;
   Acc acc;
   acc.abs = 0.0;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds);
+  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, true, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
   if constexpr (SEL) sel_feed_flush(acc.sel);
@@ -1096,7 +1102,8 @@ static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_
 // feed a selection).
 static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
                            const mq_quant_cfg* cfg, void* workspace, hipStream_t st, int sel_mode = SEL_FEED_OFF,
-                           char* sel_ws = nullptr, int64_t* sampled = nullptr) {
+                           char* sel_ws = nullptr, int64_t* sampled = nullptr, uint16_t* samples = nullptr,
+                           int64_t sample_stride = 0) {
   const int64_t n = rows * cols;
   QuantBatch b = {};
   QuantParams& p = b.common;
@@ -1142,7 +1149,9 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     it.totals = o.totals;
   }
   p.sel_mode = sel_mode;
+  p.sel_samples = samples;
   b.sel_ws = sel_ws;
+  b.sample_stride = sample_stride;
   if (sel_mode == SEL_FEED_SAMPLE) {  // errors only
     for (int i = 0; i < count; ++i) {
       BatchItem& it = b.item[i];
@@ -1190,19 +1199,14 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     *sampled = 0;
     if (scope == SC_SUBWAVE) {  // tiles of (64 / team) * 4 segments, one of every 32 tiles
       const int64_t per_tile = (int64_t)(64 >> team_log2) * 4;
-      const int64_t tiles = (p.nseg + per_tile - 1) / per_tile;
-      for (int64_t t = 0; t < tiles / 32; ++t) {
-        const int64_t first = (t * 32 + (int64_t)sample_line((uint32_t)t)) * per_tile;
-        const int64_t segs = p.nseg - first < per_tile ? p.nseg - first : per_tile;
-        *sampled += segs * p.L;
-      }
+      *sampled = ((p.nseg / per_tile) / 32) * per_tile * p.L;  // full tiles only
     } else if (scope == SC_WAVE || scope == SC_BLOCK) {  // one of every 32 segments
       *sampled = (p.nseg / 32) * p.L;
     }
     return MQ_OK;
   }
   if (sel_mode != SEL_FEED_OFF && scope != SC_SUBWAVE && scope != SC_WAVE && scope != SC_BLOCK) return MQ_ERR_UNSUPPORTED;
-  const size_t lds = sel_mode != SEL_FEED_OFF ? (size_t)2 * SEL_FEED_HASH * sizeof(uint32_t) : 0;
+  const size_t lds = sel_mode == SEL_FEED_COUNT ? (size_t)2 * SEL_FEED_HASH * sizeof(uint32_t) : 0;
 
   if (scope == SC_TENSOR) {
     for (int i = 0; i < count; ++i)
@@ -1268,9 +1272,11 @@ extern "C" int mq_quantize(const void* w, int32_t w_dtype, int64_t rows, int64_t
 static size_t sel_slices_offset(int32_t count) {
   return ((size_t)(count > MQ_MAX_BATCH ? MQ_MAX_BATCH : (count < 1 ? 1 : count)) * ws_slice_bytes() + 255) / 256 * 256;
 }
-extern "C" size_t mq_quantize_p99_batch_workspace_bytes(int32_t count, int64_t, int64_t, const mq_quant_cfg*) {
+// uint16 elements per tensor of the sample area: 1/32 of the tensor, rounded up to 128 bytes
+static int64_t sample_stride_elems(int64_t n) { return (n / 32 + 63) / 64 * 64; }
+extern "C" size_t mq_quantize_p99_batch_workspace_bytes(int32_t count, int64_t rows, int64_t cols, const mq_quant_cfg*) {
   const int32_t c = count > MQ_MAX_BATCH ? MQ_MAX_BATCH : (count < 1 ? 1 : count);
-  return sel_slices_offset(count) + (size_t)c * sel_ws_bytes();
+  return sel_slices_offset(count) + (size_t)c * sel_ws_bytes() + (size_t)c * sample_stride_elems(rows * cols) * 2;
 }
 
 extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows,
@@ -1295,6 +1301,9 @@ extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, 
   if (!aligned(workspace, 16)) return MQ_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   char* sel = static_cast<char*>(workspace) + sel_slices_offset(count);
+  const int32_t cmax = count > MQ_MAX_BATCH ? MQ_MAX_BATCH : count;
+  uint16_t* samples = reinterpret_cast<uint16_t*>(sel + (size_t)cmax * sel_ws_bytes());
+  const int64_t sstride = sample_stride_elems(n);
   for (int32_t done = 0; done < count; done += MQ_MAX_BATCH) {
     const int32_t c = count - done < MQ_MAX_BATCH ? count - done : MQ_MAX_BATCH;
     const mq_quant_item* it = items + done;
@@ -1305,8 +1314,10 @@ extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, 
     for (int i = 0; i < c; ++i) errs[i] = it[i].out.abs_err;
     if (m > 0 && sel_feed_eligible(n, m, pct)) {
       if ((rc = sel_feed_begin(sel, c, st))) return rc;
-      if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_SAMPLE, sel))) return rc;
-      if ((rc = sel_feed_bracket(sel, c, n, m, pct, st))) return rc;
+      if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_SAMPLE, sel, nullptr, samples,
+                                sstride)))
+        return rc;
+      if ((rc = sel_feed_bracket(sel, c, samples, sstride, n, m, pct, st))) return rc;
       if ((rc = quantize_launch(it, c, w_dtype, rows, cols, cfg, workspace, st, SEL_FEED_COUNT, sel))) return rc;
       if ((rc = sel_feed_finish(sel, c, errs, n, pct, p99 + done, st))) return rc;
     } else {  // small tensors, quantiles at the very ends, per-tensor or unaligned shapes: select from the dump

@@ -52,8 +52,9 @@ __host__ __device__ __forceinline__ uint32_t sample_line(uint32_t c) { return (c
 // sampled pass.  Order on one stream:
 //   sel_feed_eligible()  -> false: select from the stored array instead (mq_percentile_multi)
 //   sel_feed_begin()       clears the slices
-//   [feeding kernel, mode SEL_FEED_SAMPLE]
-//   sel_feed_bracket()     sample ranks -> bracket, clears the bracket histograms
+//   [feeding kernel, mode SEL_FEED_SAMPLE: stores the top 16 bits of its m sampled values, densely, at
+//    samples + i * sample_stride (uint16 units) for array i]
+//   sel_feed_bracket()     histogram of the samples, sample ranks -> bracket, clears the bracket histograms
 //   [feeding kernel, mode SEL_FEED_COUNT over ALL values]
 //   sel_feed_finish()      ranks inside the bracket -> results; otherwise the exact two-pass route over the
 //                          stored arrays xs[i] (enqueued always, returns at once when not needed)
@@ -61,80 +62,117 @@ enum { SEL_FEED_OFF = 0, SEL_FEED_SAMPLE = 1, SEL_FEED_COUNT = 2 };
 size_t sel_ws_bytes();
 bool sel_feed_eligible(int64_t n, int64_t m, double pct);
 int sel_feed_begin(void* ws, int count, hipStream_t st);
-int sel_feed_bracket(void* ws, int count, int64_t n, int64_t m, double pct, hipStream_t st);
+int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sample_stride, int64_t n, int64_t m,
+                     double pct, hipStream_t st);
 int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st);
 
 // ---- device side: per-lane state of a feeding kernel --------------------------------------------------
+// LDS pointers keep their address space in the type: through a generic pointer the compiler merges the table
+// update with the global overflow update into ONE flat atomic, which is several times slower than ds_add.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct SelFeed {
-  uint32_t* hkey;  // LDS [SEL_FEED_HASH]: key + 1, 0 = empty
-  uint32_t* hcnt;  // LDS [SEL_FEED_HASH]
+  lds_u32* hkey;  // LDS [SEL_FEED_HASH]: key + 1, 0 = empty
+  lds_u32* hcnt;  // LDS [SEL_FEED_HASH]
   SelWs* ws;
   uint32_t lo, nb;  // bracket (count mode)
   uint32_t below;   // this lane's count of values under the bracket
   int mode;
+  uint16_t* samples;     // sample mode: where this array's samples go
+  int64_t sample_shift;  // sample mode: element offset -> dense sample index (set by the kernel per tile)
 };
 
 // lds: SEL_FEED_HASH * 2 words of (dynamic) shared memory; every thread of the workgroup calls this.
-__device__ __forceinline__ void sel_feed_init(SelFeed& f, int mode, SelWs* ws, uint32_t* lds) {
+__device__ __forceinline__ void sel_feed_init(SelFeed& f, int mode, SelWs* ws, uint32_t* lds, uint16_t* samples) {
   f.mode = mode;
+  f.samples = samples;
+  f.sample_shift = 0;
   f.ws = ws;
-  f.hkey = lds;
-  f.hcnt = lds + SEL_FEED_HASH;
+  f.hkey = (lds_u32*)lds;
+  f.hcnt = (lds_u32*)lds + SEL_FEED_HASH;
   f.lo = 0;
   f.nb = 0;
   f.below = 0;
-  if (mode != SEL_FEED_OFF) {
+  if (mode == SEL_FEED_COUNT) {
     for (int i = threadIdx.x; i < 2 * SEL_FEED_HASH; i += blockDim.x) lds[i] = 0;
-    if (mode == SEL_FEED_COUNT) {
-      f.lo = ws->br_lo;
-      f.nb = ws->br_nb;
-    }
+    f.lo = ws->br_lo;
+    f.nb = ws->br_nb;
     __syncthreads();
   }
 }
 
 __device__ __forceinline__ void sel_feed_add(SelFeed& f, uint32_t key, uint32_t* gfine, uint32_t* gcoarse) {
   uint32_t h = (key * 2654435761u) >> 21;  // 11 bits
-  for (int probe = 0; probe < 32; ++probe) {
-    uint32_t old = atomicCAS(&f.hkey[h], 0u, key + 1u);
-    if (old == 0u || old == key + 1u) {
-      atomicAdd(&f.hcnt[h], 1u);
-      return;
+  bool placed = false;
+#pragma unroll 1
+  for (int probe = 0; probe < 32 && !placed; ++probe) {
+    // a plain read first: once a key is in the table (the common case, values repeat heavily) the insert
+    // is one fire-and-forget LDS add, no compare-and-swap round trip
+    uint32_t cur = f.hkey[h];
+    if (cur == 0u) {
+      uint32_t expect = 0u;
+      __hip_atomic_compare_exchange_strong(&f.hkey[h], &expect, key + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+      cur = expect;  // the previous content
+    }
+    if (cur == 0u || cur == key + 1u) {
+      __hip_atomic_fetch_add(&f.hcnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      placed = true;
     }
     h = (h + 1) & (SEL_FEED_HASH - 1);
   }
-  atomicAdd(&gfine[key], 1u);  // table full: straight to the global histogram
-  atomicAdd(&gcoarse[key >> 8], 1u);
+  if (!placed) {  // table full: straight to the global histogram
+    atomicAdd(&gfine[key], 1u);
+    atomicAdd(&gcoarse[key >> 8], 1u);
+  }
 }
 
-// Eight float32 values (their sign is ignored) of one lane.
-__device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e) {
+// Eight float32 values (their sign is ignored) of one lane, elements e0 .. e0 + 7 of the array.
+// Sample mode: the top 16 bits of each go to the dense sample array with one 16-byte store (a small kernel
+// histograms them afterwards: a direct LDS histogram is far cheaper than table inserts for EVERY value).
+// Count mode: the compare part is straight-line code; the table inserts of the few values inside the bracket
+// run in ONE loop (a wave iterates as often as its busiest lane has values to insert).
+__device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0) {
+  uint32_t a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = f_bits(e[i]) & 0x7fffffffu;
   if (f.mode == SEL_FEED_SAMPLE) {
+    u32x4 pk;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sel_feed_add(f, (f_bits(e[i]) >> 16) & 0x7fffu, f.ws->samp, f.ws->samp_coarse);
-  } else {
+    for (int k = 0; k < 4; ++k) pk[k] = (a[2 * k] >> 16) | (a[2 * k + 1] & 0xffff0000u);
+    *reinterpret_cast<u32x4*>(f.samples + e0 + f.sample_shift) = pk;
+    return;
+  }
+  const uint32_t lo_bits = f.lo << 16, span = f.nb << 16;
+  uint32_t mask = 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t bits = f_bits(e[i]) & 0x7fffffffu, top = bits >> 16;
-      f.below += top < f.lo ? 1u : 0u;
-      const uint32_t t = top - f.lo;  // wraps for bins under the bracket
-      if (t < f.nb) sel_feed_add(f, (t << 16) | (bits & 0xffffu), f.ws->br_fine, f.ws->br_coarse);
-    }
+  for (int i = 0; i < 8; ++i) {
+    f.below += a[i] < lo_bits ? 1u : 0u;
+    mask |= (a[i] - lo_bits < span ? 1u : 0u) << i;  // the subtraction wraps for values under the bracket
+  }
+#pragma unroll 1
+  while (mask) {
+    const int i = __builtin_ctz(mask);
+    mask &= mask - 1u;
+    // a[i] without indexing the register array
+    const uint32_t p0 = (i & 1) ? a[1] : a[0], p1 = (i & 1) ? a[3] : a[2], p2 = (i & 1) ? a[5] : a[4],
+                   p3 = (i & 1) ? a[7] : a[6];
+    const uint32_t q0 = (i & 2) ? p1 : p0, q1 = (i & 2) ? p3 : p2;
+    const uint32_t bits = (i & 4) ? q1 : q0;
+    sel_feed_add(f, bits - lo_bits, f.ws->br_fine, f.ws->br_coarse);
   }
 }
 
 // End of the feeding kernel: every thread of the workgroup calls this once.
 __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
-  if (f.mode == SEL_FEED_OFF) return;
+  if (f.mode != SEL_FEED_COUNT) return;
   __shared__ uint32_t wcnt[16];
-  if (f.mode == SEL_FEED_COUNT) {
-    uint32_t b = f.below;
+  uint32_t b = f.below;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off);
-    if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = b;
-  }
+  for (int off = 32; off > 0; off >>= 1) b += __shfl_xor(b, off);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = b;
   __syncthreads();  // all table inserts of the workgroup are done
-  if (f.mode == SEL_FEED_COUNT && threadIdx.x == 0) {
+  if (threadIdx.x == 0) {
     unsigned long long t = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += wcnt[i];
     if (t) atomicAdd(&f.ws->below, t);
@@ -148,22 +186,19 @@ __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
     c[j] = i < SEL_FEED_HASH ? f.hcnt[i] : 0u;
   }
   __syncthreads();
-  uint32_t* lco = f.hkey;  // [2 * SEL_FEED_HASH] >= SEL_BR_BINS * 256 counters
+  lds_u32* lco = f.hkey;  // [2 * SEL_FEED_HASH] >= SEL_BR_BINS * 256 counters
   for (int i = threadIdx.x; i < 2 * SEL_FEED_HASH; i += blockDim.x) lco[i] = 0;
   __syncthreads();
-  uint32_t* gfine = f.mode == SEL_FEED_SAMPLE ? f.ws->samp : f.ws->br_fine;
-  uint32_t* gcoarse = f.mode == SEL_FEED_SAMPLE ? f.ws->samp_coarse : f.ws->br_coarse;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (k[j]) {
       const uint32_t key = k[j] - 1u;
-      atomicAdd(&gfine[key], c[j]);
-      atomicAdd(&lco[key >> 8], c[j]);
+      atomicAdd(&f.ws->br_fine[key], c[j]);
+      __hip_atomic_fetch_add(&lco[key >> 8], c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
   __syncthreads();
-  const uint32_t ncoarse = f.mode == SEL_FEED_SAMPLE ? SEL_TOP_BINS / 256 : f.nb * 256;
-  for (uint32_t i = threadIdx.x; i < ncoarse; i += blockDim.x)
-    if (lco[i]) atomicAdd(&gcoarse[i], lco[i]);
+  for (uint32_t i = threadIdx.x; i < f.nb * 256; i += blockDim.x)
+    if (lco[i]) atomicAdd(&f.ws->br_coarse[i], lco[i]);
 }
 static_assert(2 * SEL_FEED_HASH >= SEL_BR_BINS * 256, "coarse overlay fits the table");

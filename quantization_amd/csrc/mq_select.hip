@@ -80,14 +80,25 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
   const int64_t nvec = n / V;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = t0; v < nvec; v += step) {
-    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
-    if constexpr (sizeof(T) == 4) {
+  constexpr int U = 4;  // loads in flight per lane
+  for (int64_t v0 = t0; v0 < nvec; v0 += U * step) {
+    u32x4 raw[U];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) atomicAdd(&lh[(raw[i] >> 16) & 0x7fffu], 1u);
-    } else {
-      atomicAdd(&lh[(raw[1] >> 16) & 0x7fffu], 1u);
-      atomicAdd(&lh[(raw[3] >> 16) & 0x7fffu], 1u);
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * step;
+      raw[u] = u32x4{0, 0, 0, 0};
+      if (v < nvec) raw[u] = reinterpret_cast<const u32x4*>(x)[v];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v0 + u * step >= nvec) break;
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&lh[(raw[u][i] >> 16) & 0x7fffu], 1u);
+      } else {
+        atomicAdd(&lh[(raw[u][1] >> 16) & 0x7fffu], 1u);
+        atomicAdd(&lh[(raw[u][3] >> 16) & 0x7fffu], 1u);
+      }
     }
   }
   for (int64_t i = nvec * V + t0; i < n; i += step) atomicAdd(&lh[(uint32_t)(key_of(x[i]) >> 48)], 1u);
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int le
     const uint32_t d = (uint32_t)(key >> shift) & 0xffffu;
     uint32_t h = (d * 2654435761u) >> 21;  // 11 bits
     for (int probe = 0; probe < 64; ++probe) {
-      uint32_t old = atomicCAS(&hkey[s][h], 0u, d + 1u);
+      uint32_t old = hkey[s][h];  // plain read first: repeated values skip the compare-and-swap
+      if (old == 0u) old = atomicCAS(&hkey[s][h], 0u, d + 1u);
       if (old == 0u || old == d + 1u) { atomicAdd(&hcnt[s][h], 1u); return; }
       h = (h + 1) & (SEL_HASH - 1);
     }
@@ -230,14 +242,25 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int le
   constexpr int V = 16 / sizeof(T);
   const int64_t nvec = n / V;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = t0; v < nvec; v += step) {
-    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
-    if constexpr (sizeof(T) == 4) {
+  constexpr int U = 4;  // loads in flight per lane
+  for (int64_t v0 = t0; v0 < nvec; v0 += U * step) {
+    u32x4 raw[U];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) put((uint64_t)(raw[i] & 0x7fffffffu) << 32);
-    } else {
-      put((((uint64_t)raw[1] << 32) | raw[0]) & 0x7fffffffffffffffull);
-      put((((uint64_t)raw[3] << 32) | raw[2]) & 0x7fffffffffffffffull);
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * step;
+      raw[u] = u32x4{0, 0, 0, 0};
+      if (v < nvec) raw[u] = reinterpret_cast<const u32x4*>(x)[v];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v0 + u * step >= nvec) break;
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) put((uint64_t)(raw[u][i] & 0x7fffffffu) << 32);
+      } else {
+        put((((uint64_t)raw[u][1] << 32) | raw[u][0]) & 0x7fffffffffffffffull);
+        put((((uint64_t)raw[u][3] << 32) | raw[u][2]) & 0x7fffffffffffffffull);
+      }
     }
   }
   for (int64_t i = nvec * V + t0; i < n; i += step) put(key_of(x[i]));
@@ -302,6 +325,29 @@ __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
   flush_top(lh, ws->samp, ws->samp_coarse);
 }
 
+// Level-0 histogram of the samples a feeding kernel stored (top 16 bits of each value, m per array).
+__global__ __launch_bounds__(1024) void k_sel_sample_u16(const SelBatch b, const uint16_t* samples, int64_t stride,
+                                                         int64_t m) {
+  extern __shared__ uint32_t lh[];
+  const uint16_t* x = samples + (int64_t)blockIdx.y * stride;
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  const int64_t nvec = m / 8;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t v = t0; v < nvec; v += step) {
+    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      atomicAdd(&lh[raw[k] & 0x7fffu], 1u);
+      atomicAdd(&lh[(raw[k] >> 16) & 0x7fffu], 1u);
+    }
+  }
+  for (int64_t i = nvec * 8 + t0; i < m; i += step) atomicAdd(&lh[x[i] & 0x7fffu], 1u);
+  __syncthreads();
+  flush_top(lh, ws->samp, ws->samp_coarse);
+}
+
 // Bins of the two sample ranks -> bracket.
 __global__ __launch_bounds__(256) void k_sel_scan_sample(const SelBatch b, const SelSampleRanks sr) {
   const uint64_t r_lo = sr.lo[blockIdx.x], r_hi = sr.hi[blockIdx.x];
@@ -353,7 +399,8 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
       const uint32_t key = (t << 16) | (bits & 0xffffu);
       uint32_t h = (key * 2654435761u) >> 20;  // 12 bits
       for (int probe = 0; probe < 64; ++probe) {
-        uint32_t old = atomicCAS(&hkey[h], 0u, key + 1u);
+        uint32_t old = hkey[h];  // plain read first: repeated values skip the compare-and-swap
+        if (old == 0u) old = atomicCAS(&hkey[h], 0u, key + 1u);
         if (old == 0u || old == key + 1u) { atomicAdd(&hcnt[h], 1u); return; }
         h = (h + 1) & (SEL_BR_HASH - 1);
       }
@@ -744,7 +791,8 @@ int sel_feed_begin(void* ws, int count, hipStream_t st) {
   return MQ_OK;
 }
 
-int sel_feed_bracket(void* ws, int count, int64_t n, int64_t m, double pct, hipStream_t st) {
+int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sample_stride, int64_t n, int64_t m,
+                     double pct, hipStream_t st) {
   int64_t k0, k1;
   double g, lo, hi;
   int rc = mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &g);
@@ -757,6 +805,12 @@ int sel_feed_bracket(void* ws, int count, int64_t n, int64_t m, double pct, hipS
     sr.lo[i] = (uint64_t)lo;
     sr.hi[i] = (uint64_t)hi;
   }
+  int64_t nb = (m / 8 + 1024 * 4 - 1) / (1024 * 4);
+  int64_t cap = 256 / count < 2 ? 2 : 256 / count;
+  MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             SEL_TOP_BINS * 4));
+  hipLaunchKernelGGL(k_sel_sample_u16, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count), dim3(1024),
+                     SEL_TOP_BINS * 4, st, b, samples, sample_stride, m);
   hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)count), dim3(256), 0, st, b, sr);
   hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / count < 8 ? 8 : 512 / count), (unsigned)count), dim3(256),
                      0, st, b);
