@@ -71,6 +71,15 @@ const char* mq_strerror(int status);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char* mq_last_hip_error(void);
 
+/*
+ * Measurement hook (no counterpart in the reference): between mq_profile_begin and mq_profile_end every full
+ * quantize launch made from the calling thread (the dominant kernel of mq_quantize / mq_quantize_batch /
+ * mq_quantize_p99_batch; not the 1/32 sampling pass) is bracketed by a pair of HIP events on its stream.
+ * mq_profile_end waits for them and returns the summed kernel time and the number of launches.
+ */
+int mq_profile_begin(void);
+int mq_profile_end(double* total_ms, int64_t* launches);
+
 /* Bytes of device workspace mq_quantize needs for this shape (reduction slots + per-block partials). */
 size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
 

@@ -50,6 +50,10 @@ def lib():
         L.mq_last_hip_error.restype = ctypes.c_char_p
         L.mq_quantize_workspace_bytes.restype = sz
         L.mq_quantize_workspace_bytes.argtypes = [i64, i64, ctypes.POINTER(QuantCfg)]
+        L.mq_profile_begin.restype = ctypes.c_int
+        L.mq_profile_begin.argtypes = []
+        L.mq_profile_end.restype = ctypes.c_int
+        L.mq_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
         L.mq_quantize.restype = ctypes.c_int
         L.mq_quantize.argtypes = [vp, i32, i64, i64, ctypes.POINTER(QuantCfg), ctypes.POINTER(QuantOut), vp, sz, vp]
         _lib = L

@@ -63,6 +63,7 @@ struct QuantParams {
 struct Acc {
   double abs;   // sum of |error|
   SelFeed sel;  // selection feed (off unless sel_mode)
+  float* xp;    // this wave's 512-float LDS exchange area for the float32 |error| stores, or null
 };
 extern __shared__ uint32_t sel_lds[];  // 2 * SEL_FEED_HASH words when sel_mode is on, else none
 
@@ -353,7 +354,12 @@ __device__ __forceinline__ uint32_t lut_round_pk(uint32_t xw, const LutConst& c)
 // ------------------------------------------------------------------------------------------------
 // one lane's 8 elements
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_abs_err(const QuantParams& p, const float* ae, int64_t e0) {
+// A lane holds 8 consecutive elements, i.e. 32 consecutive bytes of the float32 |error| array: stored straight
+// from the lane, each of the two 16-byte store instructions of a wave would fill only half of every 64 bytes it
+// touches.  When all 64 lanes are active (their 512 elements are then contiguous) the wave exchanges the
+// values through LDS so that each store instruction writes 1 KiB of consecutive bytes (measured: 8 % off the
+// whole pass).
+__device__ __forceinline__ void store_abs_err(const QuantParams& p, const float* ae, int64_t e0, float* xp) {
   if (p.abs_err_f16) {
     u32x4 a;
 #pragma unroll
@@ -363,11 +369,24 @@ __device__ __forceinline__ void store_abs_err(const QuantParams& p, const float*
     }
     *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0) = a;
   } else {
-    f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
     f32x4 a0 = {__builtin_fabsf(ae[0]), __builtin_fabsf(ae[1]), __builtin_fabsf(ae[2]), __builtin_fabsf(ae[3])};
     f32x4 a1 = {__builtin_fabsf(ae[4]), __builtin_fabsf(ae[5]), __builtin_fabsf(ae[6]), __builtin_fabsf(ae[7])};
-    o[0] = a0;
-    o[1] = a1;
+    if (xp && __builtin_amdgcn_ballot_w64(true) == ~0ull) {
+      const int lane = threadIdx.x & 63;
+      f32x4* x4 = reinterpret_cast<f32x4*>(xp);
+      x4[2 * lane] = a0;
+      x4[2 * lane + 1] = a1;
+      __builtin_amdgcn_wave_barrier();  // LDS executes a wave's accesses in order; this keeps the compiler from
+      f32x4 b0 = x4[lane], b1 = x4[64 + lane];  // moving the reads of other lanes' values above the writes
+      __builtin_amdgcn_wave_barrier();
+      f32x4* ob = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + (e0 - (int64_t)lane * 8));
+      ob[lane] = b0;
+      ob[64 + lane] = b1;
+    } else {
+      f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
+      o[0] = a0;
+      o[1] = a1;
+    }
   }
 }
 
@@ -443,7 +462,7 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
   }
   double sse = 0.0;
   if (p.need_err) {
-    if (p.abs_err) store_abs_err(p, e, e0);
+    if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
     error_sums(e, sse, acc.abs);
     if constexpr (SEL) sel_feed8(acc.sel, e, e0);
   }
@@ -500,7 +519,7 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
   }
   double sse = 0.0;
   if (p.need_err) {
-    if (p.abs_err) store_abs_err(p, e, e0);
+    if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
     error_sums(e, sse, acc.abs);
     if constexpr (SEL) sel_feed8(acc.sel, e, e0);
   }
@@ -534,7 +553,7 @@ __device__ __forceinline__ double quant8_lut_f32(const QuantParams& p, const flo
   if (p.codes) *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = c16;
   double sse = 0.0;
   if (p.need_err) {
-    if (p.abs_err) store_abs_err(p, e, e0);
+    if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
     error_sums(e, sse, acc.abs);
   }
   return sse;
@@ -565,8 +584,10 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   double acc_sse = 0.0;
+  __shared__ __attribute__((aligned(16))) float xpose[4 * 512];
   Acc acc;
   acc.abs = 0.0;
+  acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
   if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
@@ -740,9 +761,11 @@ template <int FMT, int NV, bool SEL>
 __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
+  __shared__ __attribute__((aligned(16))) float xpose[4 * 512];
   double acc_sse = 0.0;
   Acc acc;
   acc.abs = 0.0;
+  acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
   if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, false, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
@@ -753,9 +776,11 @@ template <int FMT, int NV, int THREADS, bool SEL>
 __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[96];
+  __shared__ __attribute__((aligned(16))) float xpose[(THREADS / 64) * 512];
   double acc_sse = 0.0;
   Acc acc;
   acc.abs = 0.0;
+  acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
   if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, true, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
@@ -814,8 +839,10 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   double acc_sse = 0.0;
+  __shared__ __attribute__((aligned(16))) float xpose[4 * 512];
   Acc acc;  // (this scope never feeds a selection)
   acc.abs = 0.0;
+  acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -1074,13 +1101,43 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
 }
 
 
+// ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
+#include <vector>
+static thread_local bool prof_on = false;
+static thread_local std::vector<hipEvent_t> prof_events;  // start, stop, start, stop, ...
+
+extern "C" int mq_profile_begin(void) {
+  for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+  prof_events.clear();
+  prof_on = true;
+  return MQ_OK;
+}
+
+extern "C" int mq_profile_end(double* total_ms, int64_t* launches) {
+  prof_on = false;
+  double sum = 0.0;
+  int64_t cnt = 0;
+  for (size_t i = 0; i + 1 < prof_events.size(); i += 2) {
+    MQ_HIP(hipEventSynchronize(prof_events[i + 1]));
+    float ms = 0.f;
+    MQ_HIP(hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
+    sum += ms;
+    ++cnt;
+  }
+  for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+  prof_events.clear();
+  if (total_ms) *total_ms = sum;
+  if (launches) *launches = cnt;
+  return MQ_OK;
+}
+
 // Upper bound on the grid of the streaming kernels, in 256-thread workgroups.  4 per CU keeps every
 // wave looping over several tiles so that its prefetch overlaps its compute.  MQ_MAX_BLOCKS overrides
 // it for tuning runs.
 static int64_t grid_cap() {
   static const int64_t cap = [] {
     const char* e = getenv("MQ_MAX_BLOCKS");
-    int64_t v = e ? atoll(e) : 1024;
+    int64_t v = e ? atoll(e) : 2048;
     return v < 1 ? 1 : (v > MQ_MAX_GRID ? MQ_MAX_GRID : v);
   }();
   return cap;
@@ -1215,6 +1272,15 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     int64_t cap = MQ_MAX_GRID / count < 64 ? 64 : MQ_MAX_GRID / count;
     hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < cap ? rb : cap), (unsigned)count), dim3(256), 0, st, b);
   }
+  const bool timed = prof_on && sel_mode != SEL_FEED_SAMPLE;
+  if (timed) {
+    hipEvent_t e0, e1;
+    MQ_HIP(hipEventCreate(&e0));
+    MQ_HIP(hipEventCreate(&e1));
+    prof_events.push_back(e0);
+    prof_events.push_back(e1);
+    MQ_HIP(hipEventRecord(e0, st));
+  }
   switch (cfg->format) {
     case MQ_INT_SYM:
       if (sel_mode) launch_fmt<MQ_INT_SYM, true>(scope, nv, threads, team_log2, grid, lds, st, b);
@@ -1230,6 +1296,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
       break;
   }
   MQ_HIP(hipGetLastError());
+  if (timed) MQ_HIP(hipEventRecord(prof_events.back(), st));
   if (sel_mode != SEL_FEED_SAMPLE && (o0.totals || (scope == SC_TENSOR && o0.seg_sse))) {
     hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, st, b, (int)grid.x,
                        scope == SC_TENSOR ? 1 : 0);
