@@ -408,7 +408,7 @@ __device__ __forceinline__ void error_sums(const float* e, double& sse, double& 
 //  * rint(x) for |x| < 512 is (x + 1536) - 1536 in float16 (ulp 1 in [1024, 2048), round to nearest even);
 //    the low byte of the float16 bits of 1536 + q (0x6600 + q) is q's two's-complement byte.
 //  * symmetric: |v / s| <= qmax * (1 + 2^-11) < qmax + 0.5, so the clamp to +-qmax never acts.
-template <int FMT, bool SEL>
+template <int FMT, int SEL>
 __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                               Acc& acc) {
   const uint32_t s2 = dup16(h_bits(sp.s)), zp2 = dup16(h_bits(sp.zp));
@@ -464,13 +464,13 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL) sel_feed8(acc.sel, e, e0);
+    if constexpr (SEL != SEL_FEED_OFF) sel_feed8<SEL>(acc.sel, e, e0);
   }
   return sse;
 }
 
 // Slow path: the contract element by element (any float16 input, including inf / NaN / huge v / s).
-template <int FMT, bool SEL>
+template <int FMT, int SEL>
 __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                            Acc& acc) {
   const half_t qmax_h = (half_t)p.qmax;
@@ -521,12 +521,12 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
   if (p.need_err) {
     if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL) sel_feed8(acc.sel, e, e0);
+    if constexpr (SEL != SEL_FEED_OFF) sel_feed8<SEL>(acc.sel, e, e0);
   }
   return sse;
 }
 
-template <int FMT, bool SEL>
+template <int FMT, int SEL>
 __device__ __forceinline__ double quant8(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                          Acc& acc) {
   if (__builtin_expect(sp.slow, 0)) return quant8_slow<FMT, SEL>(p, raw, sp, e0, acc);
@@ -579,7 +579,7 @@ __device__ __forceinline__ void block_partials(const QuantParams& p, double sse,
 // SC_SUBWAVE: a segment is T <= 64 lanes of one wave.  A wave streams NV x 1 KiB per iteration; the NV
 // vectors a lane holds belong to NV different segments.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int T, int NV, bool SEL>
+template <int FMT, int T, int NV, int SEL>
 __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
   constexpr int SPW = 64 / T;  // segments per wave per vector slot
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const int64_t tiles = (p.nseg + (int64_t)SPW * NV - 1) / ((int64_t)SPW * NV);
   // sampling pass of a selection: one pseudo-randomly chosen tile of every 32
   // (of the FULL tiles, so that the samples are dense: tile t of the sample holds SPW * NV whole segments)
-  const bool samp = SEL && p.sel_mode == SEL_FEED_SAMPLE;
+  constexpr bool samp = SEL == SEL_FEED_SAMPLE;
   const int64_t steps = samp ? (p.nseg / ((int64_t)SPW * NV)) / 32 : tiles;
   auto tile_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
   const bool lane_in_seg = tl < p.vecs_per_seg;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   if (gw < steps) issue(tile_of(gw), nxt);
   for (int64_t t = gw; t < steps; t += nwaves) {
     const int64_t tile = tile_of(t);
-    if constexpr (SEL) acc.sel.sample_shift = (t - tile) * ((int64_t)SPW * NV) * p.L;
+    if constexpr (SEL == SEL_FEED_SAMPLE) acc.sel.sample_shift = (t - tile) * ((int64_t)SPW * NV) * p.L;
     u32x4 raw[NV];
     bool valid[NV];
     int64_t seg[NV];
@@ -653,14 +653,14 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
     }
   }
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL) sel_feed_flush(acc.sel);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
 // SC_WAVE / SC_BLOCK: a segment (a row, or a long group) is held in the registers of one wave or one
 // workgroup, NV vectors per lane, interleaved so that every load instruction is 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------------
-template <int FMT, int NV, bool BLOCK, bool SEL>
+template <int FMT, int NV, bool BLOCK, int SEL>
 __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, double& acc_sse, Acc& acc) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t first = BLOCK ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * nw + wv;
@@ -680,7 +680,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
     }
   };
   // sampling pass of a selection: one pseudo-randomly chosen segment of every 32
-  const bool samp = SEL && p.sel_mode == SEL_FEED_SAMPLE;
+  constexpr bool samp = SEL == SEL_FEED_SAMPLE;
   const int64_t steps = samp ? p.nseg / 32 : p.nseg;
   auto seg_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
   if constexpr (PREFETCH) {
@@ -689,7 +689,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
   for (int64_t t = first; t < steps; t += stride) {
     const int64_t seg = seg_of(t);
     const int64_t base = seg * p.L;
-    if constexpr (SEL) acc.sel.sample_shift = (t - seg) * p.L;
+    if constexpr (SEL == SEL_FEED_SAMPLE) acc.sel.sample_shift = (t - seg) * p.L;
     u32x4 raw[NV];
     bool valid[NV];
 #pragma unroll
@@ -757,7 +757,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
   }
 }
 
-template <int FMT, int NV, bool SEL>
+template <int FMT, int NV, int SEL>
 __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
@@ -766,13 +766,13 @@ __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, false, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL) sel_feed_flush(acc.sel);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
 }
 
-template <int FMT, int NV, int THREADS, bool SEL>
+template <int FMT, int NV, int THREADS, int SEL>
 __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[96];
@@ -781,10 +781,10 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL) sel_feed_init(acc.sel, p.sel_mode, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, true, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL) sel_feed_flush(acc.sel);
+  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
         load8_f32(p.w, p.in_dtype, e0, w32);
         acc_sse += quant8_lut_f32(p, w32, raw[j], s32, e0, acc);
       } else {
-        acc_sse += quant8<FMT, false>(p, raw[j], sp, e0, acc);
+        acc_sse += quant8<FMT, SEL_FEED_OFF>(p, raw[j], sp, e0, acc);
       }
     }
   }
@@ -1060,7 +1060,7 @@ static bool recip_ok_cached(float c) {
   return ok;
 }
 
-template <int FMT, int NV, bool SEL>
+template <int FMT, int NV, int SEL>
 static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
   switch (team_log2) {
     case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV, SEL>), grid, dim3(256), lds, st, p); break;
@@ -1074,7 +1074,7 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
 }
 
 // SEL: the variants that feed a percentile selection (team / wave / workgroup scopes only).
-template <int FMT, bool SEL>
+template <int FMT, int SEL>
 static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
                        const QuantBatch& p) {
   if (scope == SC_SUBWAVE) {
@@ -1094,7 +1094,7 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
       if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 1024, SEL>), grid, dim3(1024), lds, st, p);
       else hipLaunchKernelGGL((k_quant_block<FMT, 16, 1024, SEL>), grid, dim3(1024), lds, st, p);
     }
-  } else if constexpr (!SEL) {
+  } else if constexpr (SEL == SEL_FEED_OFF) {
     if (scope == SC_TENSOR) hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_quant_generic<FMT>), grid, dim3(256), 0, st, p);
   }
@@ -1283,16 +1283,19 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   }
   switch (cfg->format) {
     case MQ_INT_SYM:
-      if (sel_mode) launch_fmt<MQ_INT_SYM, true>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_INT_SYM, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_INT_SYM, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_INT_SYM, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_INT_SYM, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
       break;
     case MQ_INT_ASYM:
-      if (sel_mode) launch_fmt<MQ_INT_ASYM, true>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_INT_ASYM, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_INT_ASYM, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_INT_ASYM, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_INT_ASYM, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
       break;
     default:
-      if (sel_mode) launch_fmt<MQ_LUT_FP, true>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_LUT_FP, false>(scope, nv, threads, team_log2, grid, lds, st, b);
+      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_LUT_FP, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_LUT_FP, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
+      else launch_fmt<MQ_LUT_FP, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
       break;
   }
   MQ_HIP(hipGetLastError());

@@ -83,7 +83,11 @@ struct SelFeed {
 };
 
 // lds: SEL_FEED_HASH * 2 words of (dynamic) shared memory; every thread of the workgroup calls this.
-__device__ __forceinline__ void sel_feed_init(SelFeed& f, int mode, SelWs* ws, uint32_t* lds, uint16_t* samples) {
+// MODE (SEL_FEED_SAMPLE / SEL_FEED_COUNT) is a compile-time parameter of the feeding kernel: the two passes
+// are different kernels (and show up under different names in a profile).
+template <int MODE>
+__device__ __forceinline__ void sel_feed_init(SelFeed& f, SelWs* ws, uint32_t* lds, uint16_t* samples) {
+  const int mode = MODE;
   f.mode = mode;
   f.samples = samples;
   f.sample_shift = 0;
@@ -132,11 +136,12 @@ __device__ __forceinline__ void sel_feed_add(SelFeed& f, uint32_t key, uint32_t*
 // histograms them afterwards: a direct LDS histogram is far cheaper than table inserts for EVERY value).
 // Count mode: the compare part is straight-line code; the table inserts of the few values inside the bracket
 // run in ONE loop (a wave iterates as often as its busiest lane has values to insert).
+template <int MODE>
 __device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0) {
   uint32_t a[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = f_bits(e[i]) & 0x7fffffffu;
-  if (f.mode == SEL_FEED_SAMPLE) {
+  if constexpr (MODE == SEL_FEED_SAMPLE) {
     u32x4 pk;
 #pragma unroll
     for (int k = 0; k < 4; ++k) pk[k] = (a[2 * k] >> 16) | (a[2 * k + 1] & 0xffff0000u);
@@ -164,8 +169,9 @@ __device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0
 }
 
 // End of the feeding kernel: every thread of the workgroup calls this once.
+template <int MODE>
 __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
-  if (f.mode != SEL_FEED_COUNT) return;
+  if constexpr (MODE != SEL_FEED_COUNT) return;
   __shared__ uint32_t wcnt[16];
   uint32_t b = f.below;
 #pragma unroll

@@ -15,11 +15,18 @@ from collections import defaultdict
 
 
 def per_kernel(path, counter):
+    """Counter values per kernel name.  The quantize kernels that feed a selection (<..., true>) run twice per
+    batch: the sampling pass over 1/32 of the weight and the full pass; the two are told apart by duration."""
     acc = defaultdict(list)
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0][:60]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"].split("(")[0][:60]
+            if "k_quant" in name and name.rstrip().endswith(("true>", " 1>", " 2>")):
+                dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                name += " [full pass]" if dur > 150_000 else " [sampling pass]"
+            acc[name].append(float(r["Counter_Value"]))
     return acc
 
 
@@ -35,8 +42,9 @@ def main():
         w = sum(write.get(k, [0])) / max(1, len(write.get(k, [0])))
         rows[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
                    "hbm_bytes": 2 * f * 1024 + w * 1024}
-        print(f"{k:50s} n={rows[k]['launches']:4d} read {2*f*1024/1e6:10.1f} MB  write {w*1024/1e6:10.1f} MB")
-    quant = [v for k, v in rows.items() if "k_quant" in k]
+        print(f"{k:62s} n={rows[k]['launches']:4d} read {2*f*1024/1e6:10.1f} MB  write {w*1024/1e6:10.1f} MB")
+    quant = [v for k, v in rows.items() if "k_quant" in k and "[sampling pass]" not in k
+             and ("[full pass]" in k or not any("[full pass]" in q for q in rows))]
     per_launch = sum(v["hbm_bytes"] for v in quant) / max(1, len(quant))
     out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
