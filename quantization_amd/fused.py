@@ -141,14 +141,26 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     are produced (result.abs_p99, float32 [B]); needs abs_err=torch.float32."""
     if p99 is not None and abs_err != torch.float32:
         raise ValueError("p99 needs the float32 abs_err output")
-    if w.dim() != 3:
-        raise ValueError("quantize_batch() expects [B, rows, cols]")
-    if w.dtype not in _DTYPES:
-        raise ValueError(f"unsupported weight dtype {w.dtype}")
-    if not w.is_cuda:
-        raise RuntimeError("quantize_batch() expects a ROCm device tensor")
-    w = w.contiguous()
-    B, rows, cols = w.shape
+    if isinstance(w, torch.Tensor):
+        if w.dim() != 3:
+            raise ValueError("quantize_batch() expects [B, rows, cols] or a list of [rows, cols] tensors")
+        w = w.contiguous()
+        tensors = [w[i] for i in range(w.shape[0])]
+    else:
+        # separate same-shaped tensors (the layers of a model): their pointers go to the launch as they are
+        tensors = [t.contiguous() for t in w]
+        if not tensors:
+            raise ValueError("quantize_batch() needs at least one tensor")
+        t0 = tensors[0]
+        if t0.dim() != 2 or any(t.shape != t0.shape or t.dtype != t0.dtype or t.device != t0.device for t in tensors):
+            raise ValueError("quantize_batch(): the tensors of a list must share shape [rows, cols], dtype and device")
+    w0 = tensors[0] if tensors else w
+    if w0.dtype not in _DTYPES:
+        raise ValueError(f"unsupported weight dtype {w0.dtype}")
+    if not w0.is_cuda:
+        raise RuntimeError("quantize_batch() expects ROCm device tensors")
+    B = len(tensors)
+    rows, cols = (w0.shape[-2], w0.shape[-1])
     cfg = make_cfg(fmt, bits, group_size, datatype, f32_math)
     gs = cfg.group_size
     n = rows * cols
@@ -156,7 +168,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     if gs > 0 and cols % gs:
         raise RuntimeError(f"shape '[{rows}, {cols // gs}, {gs}]' is invalid for input of size {n}")
     nseg = n // L if L else 0
-    dev = w.device
+    dev = w0.device
     res = out if out is not None else QuantResult(rows, cols, nseg)
     res.rows, res.cols, res.nseg = rows, cols, nseg
 
@@ -200,7 +212,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     items = (_QuantItem * B)()
     aed = _lib.F16 if abs_err == torch.float16 else _lib.F32
     for i in range(B):
-        items[i].w = at(w, i)
+        items[i].w = tensors[i].data_ptr()
         items[i].out = _lib.QuantOut(deq=at(b_deq, i), codes=at(b_codes, i), scale=at(b_scale, i),
                                      zero_point=at(b_zp, i), abs_err=at(b_abs, i), abs_err_dtype=aed,
                                      seg_sse=at(b_sse, i), totals=at(b_tot, i))
@@ -223,11 +235,11 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     with torch.cuda.device(dev):
         if p99 is not None:
             ws, stream = workspace(dev, L_.mq_quantize_p99_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
-            st = L_.mq_quantize_p99_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), float(p99),
+            st = L_.mq_quantize_p99_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), float(p99),
                                           res.abs_p99.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
         else:
             ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
-            st = L_.mq_quantize_batch(items, B, _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
+            st = L_.mq_quantize_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
                                       ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return res

@@ -8,8 +8,8 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .error_metrics import error_stats, percentile, true_div
-from .fused import LUT_FORMATS, quantize
+from .error_metrics import error_stats, percentile, true_div, vector_mse_stats
+from .fused import LUT_FORMATS, quantize, quantize_batch
 
 MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
 SINGLE_COLUMNS = ["datatype", "granularity", "bits", "num_channels", "groups_per_channel", "mse_tensor", "mse_rep",
@@ -77,6 +77,52 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
     if abs_p99:
         rec[5] = percentile(res.abs_err, 99).double()
     return rec
+
+
+@torch.no_grad()
+def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool = True, pct: float = 99.0,
+                  max_err_bytes: int = 8 << 30) -> torch.Tensor:
+    """layer_record(form="single") for every weight of a model at once: float64 [len(weights), len(RECORD_FIELDS)]
+    on the device, nothing synchronised.
+
+    The counterpart of the per-initializer loop of quant_error_multi_weight.py:133-151 with the quantization
+    of quant_weight.py:660-704 fused in: layers are grouped by (shape, dtype) -- a transformer has a handful --
+    and every group goes through ONE fused launch per 32 tensors (their pointers, no stacking copy); with
+    abs_p99 the P99 of |err| is selected inside that launch.  max_err_bytes bounds the float32 |err| scratch
+    of one launch."""
+    fmt, table = format_code(datatype)
+    weights = list(weights)
+    if not weights:
+        raise ValueError("model_records() needs at least one weight")
+    dev = weights[0].device
+    out = torch.zeros(len(weights), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
+    groups: Dict[Tuple, List[int]] = {}
+    for i, w in enumerate(weights):
+        if w.dim() != 2:
+            raise ValueError("model_records() takes 2-D weights")
+        groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
+    for (shape, _), idx in groups.items():
+        K, C = shape
+        L = C if granularity(group_size) == "per-channel" else group_size
+        per = K * C * 4 if abs_p99 else 1
+        chunk = max(1, min(32, max_err_bytes // per))
+        res = None
+        for lo in range(0, len(idx), chunk):
+            sel = idx[lo:lo + chunk]
+            if res is not None and len(sel) != chunk:
+                res = None  # the last, shorter chunk gets buffers of its own size
+            res = quantize_batch([weights[i] for i in sel], fmt, bits, group_size, table, deq=False, codes=False,
+                                 scale=False, abs_err=torch.float32 if abs_p99 else None, seg_sse=True, totals=True,
+                                 p99=pct if abs_p99 else None, out=res)
+            rows = torch.as_tensor(sel, device=dev)
+            rec = torch.zeros(len(sel), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
+            rec[:, 0] = K * C
+            rec[:, 1:3] = res.totals
+            rec[:, 3], rec[:, 4] = vector_mse_stats(res.seg_sse.contiguous(), L, pct)
+            if abs_p99:
+                rec[:, 5] = res.abs_p99.double()
+            out[rows] = rec
+    return out
 
 
 def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size) -> List[Dict]:

@@ -82,3 +82,23 @@ def test_histogram_merge_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_model_records_equals_per_layer_records():
+    """The batched whole-model pass (layers grouped by shape, one fused launch per group, P99 of |err| selected
+    inside it) gives the per-layer flow's records: percentiles bit for bit, sums exactly (same kernels, same
+    order), the mean of the per-vector list to rounding."""
+    import torch
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(2048, 1024), (256, 1024), (2048, 1024), (1024, 2752), (256, 1024), (2048, 1024), (96, 40)]
+    ws = [(torch.randn(*s, generator=g, device="cuda") * 0.02).half() for s in shapes]
+    for datatype, gs in (("int8_asym", 64), ("int8", None), ("fp8_e3m4", None)):
+        if gs and any(s[1] % gs for s in shapes):
+            sub = [w for w in ws if w.shape[1] % gs == 0]
+        else:
+            sub = ws
+        got = report.model_records(sub, datatype, 8, gs).cpu()
+        want = torch.stack([report.layer_record(w, datatype, 8, gs, form="single") for w in sub]).cpu()
+        assert torch.equal(got[:, [0, 1, 2, 4, 5]], want[:, [0, 1, 2, 4, 5]]), (datatype, gs)
+        assert torch.allclose(got[:, 3], want[:, 3], rtol=1e-12, atol=0), (datatype, gs)
