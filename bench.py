@@ -194,15 +194,21 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # one rank per GPU over RCCL; MQ_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
+        backend = os.environ.get("MQ_BENCH_BACKEND", "nccl")
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.lib()
 
     wl = Workload(args.workload, device, rank)
-    gathered = torch.zeros(world, wl.tensors, 5, dtype=torch.float64, device=device) if world > 1 else None
+    gathered = torch.zeros(world * wl.tensors, 5, dtype=torch.float64, device=device) if world > 1 else None
 
     def one_step():
         stats = wl.step()
