@@ -13,7 +13,7 @@ typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 #define MQ_WAVE 64
-#define MQ_MAX_GRID 2048  // 256 CUs x 8 resident 256-thread blocks
+#define MQ_MAX_GRID 16384  // upper bound of any grid.x (the per-workgroup partial sums live in the workspace)
 
 // ---- host side error plumbing -------------------------------------------------------------------
 void mq_set_hip_error(hipError_t e, const char* what);

@@ -1131,13 +1131,14 @@ extern "C" int mq_profile_end(double* total_ms, int64_t* launches) {
   return MQ_OK;
 }
 
-// Upper bound on the grid of the streaming kernels, in 256-thread workgroups.  4 per CU keeps every
-// wave looping over several tiles so that its prefetch overlaps its compute.  MQ_MAX_BLOCKS overrides
-// it for tuning runs.
+// Upper bound on the grid of the streaming kernels, in 256-thread workgroups.  Measured on the 16 x 4096^2
+// batch: 1024 .. 3072 workgroups (every wave resident for the whole launch, looping over many tiles) run the
+// full pass in ~518 us, 8192 in ~490 us, 32768 and more lose again (per-workgroup epilogues).  MQ_MAX_BLOCKS
+// overrides it for tuning runs.
 static int64_t grid_cap() {
   static const int64_t cap = [] {
     const char* e = getenv("MQ_MAX_BLOCKS");
-    int64_t v = e ? atoll(e) : 2048;
+    int64_t v = e ? atoll(e) : 8192;
     return v < 1 ? 1 : (v > MQ_MAX_GRID ? MQ_MAX_GRID : v);
   }();
   return cap;
