@@ -175,26 +175,36 @@ __device__ __forceinline__ double team_sum(double v) {
 // ------------------------------------------------------------------------------------------------
 // loads: 8 consecutive elements of the caller's tensor as packed float16 (w.to(torch.float16))
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32x4 load8_f16(const void* w, int dtype, int64_t e) {
-  if (dtype == MQ_F16) return *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e);
+// bfloat16 -> float16 (round to nearest even, as w.to(torch.float16) does) for 8 packed elements
+__device__ __forceinline__ u32x4 bf16x8_to_f16(u32x4 b) {
   u32x4 out;
-  if (dtype == MQ_BF16) {
-    u32x4 b = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      h16x2 h;
-      h[0] = (half_t)f_from_bits(b[k] << 16);
-      h[1] = (half_t)f_from_bits(b[k] & 0xffff0000u);
-      out[k] = as_u32(h);
-    }
-    return out;
+  for (int k = 0; k < 4; ++k) {
+    h16x2 h;
+    h[0] = (half_t)f_from_bits(b[k] << 16);
+    h[1] = (half_t)f_from_bits(b[k] & 0xffff0000u);
+    out[k] = as_u32(h);
   }
+  return out;
+}
+
+// Two-step load for the software-pipelined kernels: load8_raw only moves bytes (float16 / bfloat16: one
+// 16-byte load that can stay in flight; float32: converted at once, it needs two loads anyway), raw_to_f16
+// converts bfloat16 when the values are consumed.
+__device__ __forceinline__ u32x4 load8_raw(const void* w, int dtype, int64_t e) {
+  if (dtype != MQ_F32) return *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e);
+  u32x4 out;
   const f32x4* p = reinterpret_cast<const f32x4*>(static_cast<const float*>(w) + e);
   f32x4 a = p[0], c = p[1];
   h16x2 h0 = {(half_t)a[0], (half_t)a[1]}, h1 = {(half_t)a[2], (half_t)a[3]};
   h16x2 h2 = {(half_t)c[0], (half_t)c[1]}, h3 = {(half_t)c[2], (half_t)c[3]};
   out[0] = as_u32(h0); out[1] = as_u32(h1); out[2] = as_u32(h2); out[3] = as_u32(h3);
   return out;
+}
+__device__ __forceinline__ u32x4 raw_to_f16(u32x4 raw, int dtype) { return dtype == MQ_BF16 ? bf16x8_to_f16(raw) : raw; }
+
+__device__ __forceinline__ u32x4 load8_f16(const void* w, int dtype, int64_t e) {
+  return raw_to_f16(load8_raw(w, dtype, e), dtype);
 }
 
 // the same 8 elements widened to float32 without passing through float16 (w.to(torch.float32))
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       int64_t sg = (tile * NV + j) * SPW + team;
-      dst[j] = (lane_in_seg && sg < p.nseg) ? load8_f16(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
+      dst[j] = (lane_in_seg && sg < p.nseg) ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
                                             : u32x4{0, 0, 0, 0};
     }
   };
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
     int64_t seg[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      raw[j] = nxt[j];
+      raw[j] = raw_to_f16(nxt[j], p.in_dtype);
       seg[j] = (tile * NV + j) * SPW + team;
       valid[j] = lane_in_seg && seg[j] < p.nseg;
     }
@@ -676,7 +686,7 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       int v = j * tcount + tid;
-      dst[j] = v < p.vecs_per_seg ? load8_f16(p.w, p.in_dtype, sg * p.L + (int64_t)v * 8) : u32x4{0, 0, 0, 0};
+      dst[j] = v < p.vecs_per_seg ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)v * 8) : u32x4{0, 0, 0, 0};
     }
   };
   // sampling pass of a selection: one pseudo-randomly chosen segment of every 32
@@ -696,10 +706,12 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
     for (int j = 0; j < NV; ++j) valid[j] = j * tcount + tid < p.vecs_per_seg;
     if constexpr (PREFETCH) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) raw[j] = nxt[j];
+      for (int j = 0; j < NV; ++j) raw[j] = raw_to_f16(nxt[j], p.in_dtype);
       if (t + stride < steps) issue(seg_of(t + stride), nxt);
     } else {
       issue(seg, raw);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[j] = raw_to_f16(raw[j], p.in_dtype);
     }
     SegP sp;
     if constexpr (FMT == MQ_INT_ASYM) {
