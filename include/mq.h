@@ -24,7 +24,12 @@ typedef enum { MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2, MQ_F64 = 3 } mq_dtype;
 typedef enum {
   MQ_INT_SYM = 0,  /* quant_int / _int_quant_meta(asym=False)      quant_weight.py:229-266, :768-775 */
   MQ_INT_ASYM = 1, /* quant_int_asym / _int_quant_meta(asym=True)  quant_weight.py:298-335, :756-766 */
-  MQ_LUT_FP = 2    /* quant_datatype / _fp_quant_meta value tables quant_weight.py:503-601, :778-872 */
+  MQ_LUT_FP = 2,   /* quant_datatype / _fp_quant_meta value tables quant_weight.py:503-601, :778-872:
+                      tables without subnormals (FP8_E4M3 :114, FP8_E3M4 :91, FP8_E2M5 :65)              */
+  MQ_LUT_FP_SUB = 3 /* the same for tables WITH subnormals: +-m*2^(1-bias-M) below 2^(1-bias), then
+                      +-(1+m/2^M)*2^(e-bias), e = 1 .. 2^E-1: FP4_E2M1 (2,1,0) :22, FP5_E2M2 (2,2,-1) :38,
+                      FP5_E3M1 (3,1,0) :40, FP6_E2M3 (2,3,-2) :50, FP6_E3M2 (3,2,-1) :56; exp_bits = 0 is the
+                      uniform grid alone: INTn lists as tables (n-1 mantissa bits, bias 2-n) :10,:18,:34,:44,:64 */
 } mq_format;
 
 typedef enum {

@@ -30,7 +30,19 @@ F16, BF16, F32 = 0, 1, 2
 INT_SYM, INT_ASYM, LUT = 0, 1, 2
 
 # (exponent bits, mantissa bits, bias) of the LUT formats on the hot path
-LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3)}
+# name -> (exp_bits, man_bits, bias) of the value-table formats that have a closed form
+# (reference: quant_weight.py).  Without subnormals: +-(1 + m/2^M) * 2^(e - bias) over ALL exponent codes, the
+# (e=0, m=0) code being the single zero: FP8_E4M3 :114-138, FP8_E3M4 :91-113, FP8_E2M5 :65-90.
+# With subnormals (LUT_SUBNORMAL): +-m * 2^(1-bias-M) for e = 0: FP4_E2M1 :22, FP5_E2M2 :38, FP5_E3M1 :40,
+# FP6_E2M3 :50, FP6_E3M2 :56; exp_bits 0 = the uniform grid alone, i.e. the INTn lists used as tables
+# (:10, :18, :34, :44, :64) when quant_datatype is called with an 'int*' name.
+LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3), "fp8_e2m5": (2, 5, 1),
+               "fp4": (2, 1, 0), "fp5": (2, 2, -1), "fp5_e2m2": (2, 2, -1), "fp5_e3m1": (3, 1, 0),
+               "fp6": (2, 3, -2), "fp6_e2m3": (2, 3, -2), "fp6_e3m2": (3, 2, -1),
+               "int3": (0, 2, -1), "int4": (0, 3, -2), "int5": (0, 4, -3), "int6": (0, 5, -4), "int8": (0, 7, -6)}
+LUT_SUBNORMAL = {"fp4", "fp5", "fp5_e2m2", "fp5_e3m1", "fp6", "fp6_e2m3", "fp6_e3m2",
+                 "int3", "int4", "int5", "int6", "int8"}
+LUT_SUB = 3
 
 
 class _Cfg(ctypes.Structure):
@@ -71,13 +83,18 @@ def lib():
         L.orc_h2f_soft.restype = ctypes.c_float
         L.orc_build_lut.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
         L.orc_build_lut.restype = ctypes.c_int
+        L.orc_build_lut_sub.argtypes = L.orc_build_lut.argtypes
+        L.orc_build_lut_sub.restype = ctypes.c_int
+        L.orc_lut_round_f16_sub.argtypes = L.orc_lut_round_f16.argtypes
+        L.orc_lut_round_f16_sub.restype = ctypes.c_uint16
         _LIB = L
     return _LIB
 
 
-def build_lut(ebits, mbits, bias):
+def build_lut(ebits, mbits, bias, subnormals=False):
     out = np.zeros(1024, np.float64)
-    n = lib().orc_build_lut(ebits, mbits, bias, out.ctypes.data, 1024)
+    fn = lib().orc_build_lut_sub if subnormals else lib().orc_build_lut
+    n = fn(ebits, mbits, bias, out.ctypes.data, 1024)
     return out[:n].copy()
 
 
@@ -101,6 +118,8 @@ def quantize(w, dtype, fmt, bits=8, group_size=None, datatype=None, lut_f32_path
     cfg = _Cfg(fmt=fmt, bits=bits, group_size=gs, lut_f32_path=int(bool(lut_f32_path)))
     if fmt == LUT:
         cfg.ebits, cfg.mbits, cfg.bias = LUT_FORMATS[datatype]
+        if datatype in LUT_SUBNORMAL:
+            cfg.fmt = LUT_SUB
     n = K * C
     L = n if gs == -1 else (C if gs <= 0 else gs)
     nseg = n // L if L else 0

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmq.so")
 
 F16, BF16, F32 = 0, 1, 2
-INT_SYM, INT_ASYM, LUT_FP = 0, 1, 2
+INT_SYM, INT_ASYM, LUT_FP, LUT_FP_SUB = 0, 1, 2, 3
 
 OK, ERR_ARG, ERR_GROUP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_ALIGN = 0, -1, -2, -3, -4, -5, -6
 

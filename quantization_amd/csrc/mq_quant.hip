@@ -30,6 +30,10 @@ enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
 
 struct LutConst {
   uint32_t shift, half, maxb, minpos, mid;  // rounding constants in the float16 (or float32) bit domain
+  // tables WITH subnormals (MQ_LUT_FP_SUB): values m * 2^(1-bias-M) below sub_lim = 2^(1-bias), then
+  // (1 + m / 2^M) * 2^(e-bias) up to sub_max; rounded per element in float64 (lut_round_sub)
+  int32_t sub, man;
+  double sub_lim, sub_max;
 };
 
 struct QuantParams {
@@ -310,6 +314,7 @@ __device__ __forceinline__ SegP params_absmax(uint32_t amax_bits, const QuantPar
   sp.zp = (half_t)0;
   sp.slow = amax_bits >= 0x7c00u;  // inf or NaN in the segment
   if (sp.slow) finish_params(sp, clamp_scale((half_t)((float)h_from_bits(amax_bits) / p.qmax)));
+  sp.slow = sp.slow || p.lut.sub != 0;  // tables with subnormals are rounded per element
   return sp;
 }
 // mm: min in the low half, max in the high half
@@ -359,6 +364,33 @@ __device__ __forceinline__ uint32_t lut_round_pk(uint32_t xw, const LutConst& c)
   uint32_t z = pk_sub_u16_sat(an, dup16(c.mid));  // nonzero iff |x| is past the 0 / minpos midpoint
   uint32_t m = pk_sub_u16(0u, pk_min_u16(z, 0x00010001u));  // 0xffff or 0 per half
   return ((xw & 0x80008000u) | r) & m;  // zero is +0
+}
+
+// Nearest value of a table with subnormals, ties toward -inf, NaN -> +0, zero is +0.  Below sub_lim the
+// table is the uniform grid m * 2^(1-bias-M): adding sub_lim moves |x| into the binade [sub_lim, 2 sub_lim)
+// whose M-bit mantissa grid is exactly that grid (the sum is exact in float64 for float16 and float32 x
+// near every tie), so one mantissa rounding serves both ranges.  Ties: a positive tie goes to the smaller
+// magnitude, a negative one to the larger (the reference picks entry i iff mid[i-1] < x <= mid[i]).
+__device__ __forceinline__ float lut_round_sub(float x, const LutConst& c) {
+  if (x != x) return 0.0f;
+  const bool neg = x < 0.0f;
+  const double a = __builtin_fabs((double)x);
+  double r;
+  if (a >= c.sub_max) {
+    r = c.sub_max;
+  } else {
+    const bool low = a < c.sub_lim;
+    const double y = low ? a + c.sub_lim : a;
+    const int sh = 52 - c.man;
+    const uint64_t half = 1ull << (sh - 1);
+    uint64_t b = __builtin_bit_cast(uint64_t, y);
+    b = (b + (neg ? half : half - 1ull)) & ~((1ull << sh) - 1ull);
+    r = __builtin_bit_cast(double, b);
+    if (low) r -= c.sub_lim;
+    if (r > c.sub_max) r = c.sub_max;
+  }
+  if (r == 0.0) return 0.0f;
+  return neg ? -(float)r : (float)r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -506,7 +538,8 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
       d = (q - sp.zp) * sp.s;
       code = (uint32_t)(int)q & 0xffu;
     } else {
-      code = lut_round_bits(h_bits(x), 0x8000u, 0x7c00u, p.lut);
+      code = p.lut.sub ? h_bits((half_t)lut_round_sub((float)x, p.lut))
+                       : lut_round_bits(h_bits(x), 0x8000u, 0x7c00u, p.lut);
       d = h_from_bits(code) * sp.s;
     }
     uint32_t db = h_bits(d);
@@ -552,7 +585,8 @@ __device__ __forceinline__ double quant8_lut_f32(const QuantParams& p, const flo
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     float x = w32[i] / s;
-    float q = f_from_bits(lut_round_bits(f_bits(x), 0x80000000u, 0x7f800000u, p.lut));
+    float q = p.lut.sub ? lut_round_sub(x, p.lut)
+                        : f_from_bits(lut_round_bits(f_bits(x), 0x80000000u, 0x7f800000u, p.lut));
     float t = q * s;
     uint32_t db = f2h_bits(t), cb = f2h_bits(q);
     if (i & 1) { dq[i >> 1] |= db << 16; c16[i >> 1] |= cb << 16; } else { dq[i >> 1] = db; c16[i >> 1] = cb; }
@@ -961,7 +995,8 @@ __global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
         d = (q - sp.zp) * sp.s;
         code = (uint32_t)(int)q & 0xffu;
       } else {
-        code = lut_round_bits(h_bits(x), 0x8000u, 0x7c00u, p.lut);
+        code = p.lut.sub ? h_bits((half_t)lut_round_sub((float)x, p.lut))
+                         : lut_round_bits(h_bits(x), 0x8000u, 0x7c00u, p.lut);
         d = h_from_bits(code) * sp.s;
       }
       if (p.deq) p.deq[base + i] = (uint16_t)h_bits(d);
@@ -1031,6 +1066,20 @@ static int ilog2_ceil(int64_t x) {
 
 static bool lut_consts(const mq_quant_cfg* cfg, bool f32, LutConst* c, float* lutmax) {
   const int E = cfg->exp_bits, M = cfg->man_bits, B = cfg->exp_bias;
+  *c = LutConst{};
+  if (cfg->format == MQ_LUT_FP_SUB) {
+    // E == 0: the uniform grid alone (the INTn value lists used as tables); values must be float16 numbers
+    if (E < 0 || E > 5 || M < 1 || M > 9) return false;
+    const double lim = ldexp(1.0, 1 - B), u = ldexp(1.0, 1 - B - M);
+    const double mx = E == 0 ? lim - u : ldexp(2.0 - ldexp(1.0, -M), (1 << E) - 1 - B);
+    if (!(mx <= 65504.0) || !(u >= ldexp(1.0, -14))) return false;
+    c->sub = 1;
+    c->man = M;
+    c->sub_lim = lim;
+    c->sub_max = mx;
+    *lutmax = (float)mx;
+    return true;
+  }
   if (E < 1 || E > 5 || M < 1 || M > 9) return false;
   const int emax = (1 << E) - 1 - B;  // largest exponent, smallest is -B
   const int mant = f32 ? 23 : 10, ebias = f32 ? 127 : 15;
@@ -1182,6 +1231,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   p.n = n;
   p.L = cfg->group_size == -1 ? n : (cfg->group_size <= 0 ? cols : cfg->group_size);
   p.nseg = n / p.L;
+  const int fmt = cfg->format == MQ_LUT_FP_SUB ? MQ_LUT_FP : cfg->format;  // same kernels, per-element rounding
   if (cfg->format == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
   else if (cfg->format == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
   else if (!lut_consts(cfg, cfg->f32_math != 0, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
@@ -1205,7 +1255,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
       return MQ_ERR_ARG;
     if (!aligned(items[i].w, esz) || !aligned(o.deq, 2) || !aligned(o.scale, 2) || !aligned(o.zero_point, 2) ||
         !aligned(o.seg_sse, 8) || !aligned(o.totals, 8) || !aligned(o.abs_err, p.abs_err_f16 ? 2 : 4) ||
-        (cfg->format == MQ_LUT_FP && !aligned(o.codes, 2)))
+        (fmt == MQ_LUT_FP && !aligned(o.codes, 2)))
       return MQ_ERR_ALIGN;
     vec_ok = vec_ok && aligned(items[i].w, 16) && aligned(o.deq, 16) && aligned(o.codes, 16) && aligned(o.abs_err, 16);
     BatchItem& it = b.item[i];
@@ -1294,7 +1344,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     prof_events.push_back(e1);
     MQ_HIP(hipEventRecord(e0, st));
   }
-  switch (cfg->format) {
+  switch (fmt) {
     case MQ_INT_SYM:
       if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_INT_SYM, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
       else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_INT_SYM, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
@@ -1326,9 +1376,10 @@ extern "C" int mq_quantize_batch(const mq_quant_item* items, int32_t count, int3
                                  void* hip_stream) {
   if (!cfg || count < 0 || rows < 0 || cols < 0 || (count > 0 && !items)) return MQ_ERR_ARG;
   if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
-  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && cfg->format != MQ_LUT_FP) return MQ_ERR_ARG;
-  if (cfg->format != MQ_LUT_FP && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
-  if (cfg->f32_math && !(cfg->format == MQ_LUT_FP && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
+  const bool is_lut = cfg->format == MQ_LUT_FP || cfg->format == MQ_LUT_FP_SUB;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && !is_lut) return MQ_ERR_ARG;
+  if (!is_lut && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math && !(is_lut && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
   if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
   if (count == 0 || rows * cols == 0) return MQ_OK;
   for (int32_t i = 0; i < count; ++i)
@@ -1368,9 +1419,10 @@ extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, 
   if (!cfg || count < 0 || rows < 0 || cols < 0 || (count > 0 && !items) || !p99) return MQ_ERR_ARG;
   if (!(pct >= 0.0 && pct <= 100.0)) return MQ_ERR_ARG;
   if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
-  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && cfg->format != MQ_LUT_FP) return MQ_ERR_ARG;
-  if (cfg->format != MQ_LUT_FP && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
-  if (cfg->f32_math && !(cfg->format == MQ_LUT_FP && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
+  const bool is_lut = cfg->format == MQ_LUT_FP || cfg->format == MQ_LUT_FP_SUB;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && !is_lut) return MQ_ERR_ARG;
+  if (!is_lut && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math && !(is_lut && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
   if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
   const int64_t n = rows * cols;
   if (count == 0) return MQ_OK;

@@ -11,9 +11,18 @@ import torch
 
 from . import _lib
 
-# name -> (exp_bits, man_bits, bias) of the value-table formats
-# (reference: quant_weight.py FP8_E3M4 :91-113, FP8_E4M3 :114-138)
-LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3)}
+# name -> (exp_bits, man_bits, bias) of the value-table formats that have a closed form
+# (reference: quant_weight.py).  Without subnormals: +-(1 + m/2^M) * 2^(e - bias) over ALL exponent codes, the
+# (e=0, m=0) code being the single zero: FP8_E4M3 :114-138, FP8_E3M4 :91-113, FP8_E2M5 :65-90.
+# With subnormals (LUT_SUBNORMAL): +-m * 2^(1-bias-M) for e = 0: FP4_E2M1 :22, FP5_E2M2 :38, FP5_E3M1 :40,
+# FP6_E2M3 :50, FP6_E3M2 :56; exp_bits 0 = the uniform grid alone, i.e. the INTn lists used as tables
+# (:10, :18, :34, :44, :64) when quant_datatype is called with an 'int*' name.
+LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3), "fp8_e2m5": (2, 5, 1),
+               "fp4": (2, 1, 0), "fp5": (2, 2, -1), "fp5_e2m2": (2, 2, -1), "fp5_e3m1": (3, 1, 0),
+               "fp6": (2, 3, -2), "fp6_e2m3": (2, 3, -2), "fp6_e3m2": (3, 2, -1),
+               "int3": (0, 2, -1), "int4": (0, 3, -2), "int5": (0, 4, -3), "int6": (0, 5, -4), "int8": (0, 7, -6)}
+LUT_SUBNORMAL = {"fp4", "fp5", "fp5_e2m2", "fp5_e3m1", "fp6", "fp6_e2m3", "fp6_e3m2",
+                 "int3", "int4", "int5", "int6", "int8"}
 
 _DTYPES = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
 _workspaces = {}
@@ -61,6 +70,8 @@ def make_cfg(fmt, bits=8, group_size=None, datatype=None, f32_math=False):
     cfg = _lib.QuantCfg(format=fmt, bits=int(bits), group_size=gs, f32_math=int(bool(f32_math)))
     if fmt == _lib.LUT_FP:
         cfg.exp_bits, cfg.man_bits, cfg.exp_bias = LUT_FORMATS[datatype]
+        if datatype in LUT_SUBNORMAL:
+            cfg.format = _lib.LUT_FP_SUB
     return cfg
 
 

@@ -1,14 +1,17 @@
-"""Drop-in for the reference's quant_utils/quant_weight.py on the 8-bit hot path, running on MI355X.
+"""Drop-in for the reference's quant_utils/quant_weight.py, running on MI355X.
 
 Same function names, argument meaning, return shapes/dtypes and exception types as the reference
 (citations are into /root/reference/quant_utils/quant_weight.py); the arithmetic runs in the fused HIP
 kernel behind include/mq.h.  A host tensor is moved to the current ROCm device and the result moved
 back, so the reference's CPU-tensor call sites keep working; there is no CPU compute path.
 
-Supported on the device: symmetric / asymmetric INT with 2..8 bits, and the value-table formats
-fp8_e4m3 and fp8_e3m4, each per-tensor (group_size == -1), per-channel (None / 0 / other negatives)
-or per-group (> 0).  Other table formats of the reference (fp3..fp6, flint, fp8_e2m5, fp8_e5m2, MX,
-mixed search) are not implemented and raise NotImplementedError.
+Supported on the device: symmetric / asymmetric INT with 2..8 bits, and every value-table format of the
+reference that is a regular minifloat grid -- fp8_e4m3, fp8_e3m4, fp8_e2m5 (no subnormals: packed fast
+path), fp4, fp5 / fp5_e2m2, fp5_e3m1, fp6 / fp6_e2m3, fp6_e3m2 and the INTn lists when passed to
+quant_datatype (tables with subnormals: per-element path) -- each per-tensor (group_size == -1),
+per-channel (None / 0 / other negatives) or per-group (> 0).  The irregular tables (fp3*, flint*, the
+*_er_* / *_ea_* variants), fp8_e5m2's float32 path, MX and the mixed-datatype search are not implemented
+and raise NotImplementedError.
 """
 from typing import Optional
 

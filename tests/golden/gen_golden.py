@@ -11,7 +11,10 @@ Files written:
   quant_exhaustive.npz  all 65 536 float16 bit patterns as one 256x256 matrix (non-finite ones
                         replaced by 0) and the reference outputs for per-channel / g=128
   lut_domain.npz        x-domain sweep of the LUT rounding: rows whose scale is exactly 1
-  lut_tables.json       the reference's FP8_E4M3 / FP8_E3M4 value lists
+  lut_tables.json       the reference's value lists of every table format the kernels support
+  quant_more_formats.npz  the formats beyond the 8-bit headline set: value tables fp4, fp5_e2m2, fp5_e3m1,
+                        fp6_e2m3, fp6_e3m2, fp8_e2m5 and the INTn lists used as tables (int3, int4, int6),
+                        4-bit INT sym / asym; small inputs, all float16 patterns, the rounding-domain sweep
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
@@ -147,10 +150,67 @@ def gen_lut_domain():
     print("lut_domain.npz")
 
 
+MORE_TABLES = [(4, "fp4"), (5, "fp5_e2m2"), (5, "fp5_e3m1"), (6, "fp6_e2m3"), (6, "fp6_e3m2"), (8, "fp8_e2m5"),
+               (3, "int3"), (4, "int4"), (6, "int6")]
+ALL_TABLES = [(8, "fp8_e4m3"), (8, "fp8_e3m4"), (5, "fp5"), (6, "fp6"), (5, "int5"), (8, "int8")] + MORE_TABLES
+_MAPPING = {3: qw.DATATYPE_MAPPING_3_BIT, 4: qw.DATATYPE_MAPPING_4_BIT, 5: qw.DATATYPE_MAPPING_5_BIT,
+            6: qw.DATATYPE_MAPPING_6_BIT, 8: qw.DATATYPE_MAPPING_8_BIT}
+
+
 def gen_lut_tables():
     with open(os.path.join(HERE, "lut_tables.json"), "w") as f:
-        json.dump({k: list(map(float, qw.DATATYPE_MAPPING_8_BIT[k])) for k in ("fp8_e4m3", "fp8_e3m4")}, f)
+        json.dump({name: list(map(float, _MAPPING[bits][name])) for bits, name in ALL_TABLES}, f)
     print("lut_tables.json")
+
+
+def gen_more_formats():
+    gen = torch.Generator().manual_seed(7)
+    torch.manual_seed(7)
+    K, C = 8, 512
+    arrays = {}
+    inputs = {name: w.half() for name, w in distributions(K, C, gen)
+              if name in ("normal", "heavy", "zerorows", "student_t")}
+    bits = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    allf16 = torch.from_numpy(bits.view(np.int16).copy()).view(torch.float16)
+    inputs["exhaustive"] = torch.where(torch.isfinite(allf16), allf16, torch.zeros_like(allf16))
+    for name, w in inputs.items():
+        arrays[f"in/{name}"] = bits16(w)
+    for wq_bits, fmt in MORE_TABLES:
+        for name, w in inputs.items():
+            for gs in ([None, 128] if name == "exhaustive" else [None, 64, -1]):
+                d, q, s = qw._fp_quant_meta(w, wq_bits=wq_bits, datatype=fmt, group_size=gs)
+                d2 = qw.quant_datatype(w, wq_bits=wq_bits, datatype=fmt, group_size=gs)
+                pre = f"out/{name}/{fmt}/{gs_key(gs)}/"
+                arrays[pre + "deq"], arrays[pre + "q"] = bits16(d), bits16(q)
+                arrays[pre + "scale"] = bits16(s.reshape(-1))
+                arrays[pre + "deq_quant_datatype"] = bits16(d2.reshape_as(d))
+        # rounding-domain sweep: rows padded with the table maximum, so scale == 1 and x is the element itself
+        lutmax = float(max(abs(v) for v in _MAPPING[wq_bits][fmt]))
+        keep = allf16.reshape(-1)
+        keep = keep[torch.isfinite(keep) & (keep.abs() <= lutmax)]
+        Cd = 1024
+        rows = (keep.numel() + Cd - 2) // (Cd - 1)
+        w = torch.zeros(rows, Cd, dtype=torch.float16)
+        w[:, 0] = lutmax
+        flat = torch.zeros(rows * (Cd - 1), dtype=torch.float16)
+        flat[: keep.numel()] = keep
+        w[:, 1:] = flat.reshape(rows, Cd - 1)
+        d, q, s = qw._fp_quant_meta(w, wq_bits=wq_bits, datatype=fmt, group_size=None)
+        assert torch.all(s == 1.0)
+        arrays[f"domain/{fmt}/in"], arrays[f"domain/{fmt}/q"] = bits16(w), bits16(q)
+    for asym in (False, True):
+        fmt = "int4_asym" if asym else "int4"
+        for name, w in inputs.items():
+            for gs in ([None, 128] if name == "exhaustive" else [None, 64, -1]):
+                d, q, s, zp = qw._int_quant_meta(w, wq_bits=4, asym=asym, group_size=gs)
+                pre = f"out/{name}/{fmt}.int/{gs_key(gs)}/"
+                arrays[pre + "deq"] = bits16(d)
+                arrays[pre + "q"] = q.contiguous().view(torch.uint8).numpy().copy()
+                arrays[pre + "scale"] = bits16(s.reshape(-1))
+                if zp is not None:
+                    arrays[pre + "zp"] = bits16(zp.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, "quant_more_formats.npz"), **arrays)
+    print("quant_more_formats.npz", len(arrays), "arrays")
 
 
 def digest(a):
@@ -219,7 +279,12 @@ def gen_error_stats():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "more":   # only the files added for the extra formats
+        gen_lut_tables()
+        gen_more_formats()
+        sys.exit(0)
     gen_lut_tables()
+    gen_more_formats()
     gen_quant_small()
     gen_exhaustive()
     gen_lut_domain()

@@ -41,3 +41,25 @@ def exhaustive_expected(fmt, gs):
     z = npz("quant_exhaustive.npz")
     pre = f"out/{fmt}/{gs_key(gs)}/"
     return z["in"], {k[len(pre):]: z[k] for k in z if k.startswith(pre)}
+
+
+# formats beyond the 8-bit headline set (quant_more_formats.npz): (wq_bits, table name)
+MORE_TABLES = [(4, "fp4"), (5, "fp5_e2m2"), (5, "fp5_e3m1"), (6, "fp6_e2m3"), (6, "fp6_e3m2"), (8, "fp8_e2m5"),
+               (3, "int3"), (4, "int4"), (6, "int6")]
+
+
+def more_cases(fmt_key):
+    """-> list of (input name, array, group size, expected dict) stored for one format key
+    ('fp4', ..., or 'int4.int' / 'int4_asym.int' for the 4-bit INT paths)."""
+    z = npz("quant_more_formats.npz")
+    out = []
+    for k in sorted(z):
+        if not k.startswith("out/") or not k.endswith("/deq"):
+            continue
+        _, name, fmt, gk, _ = k.split("/")
+        if fmt != fmt_key:
+            continue
+        pre = f"out/{name}/{fmt}/{gk}/"
+        exp = {kk[len(pre):]: z[kk] for kk in z if kk.startswith(pre)}
+        out.append((name, z[f"in/{name}"], None if gk == "none" else int(gk), exp))
+    return out

@@ -325,3 +325,36 @@ def test_fused_p99_survives_a_misleading_sample():
     want = np.float32(np.percentile(a.abs_err.cpu().numpy().ravel(), 99))
     assert a.abs_p99.cpu().numpy().tobytes() == np.array([want], np.float32).tobytes()
     assert want > 0
+
+
+@pytest.mark.parametrize("bits,fmt", gu.MORE_TABLES)
+def test_golden_more_table_formats(qa, bits, fmt):
+    """Value tables with subnormals (fp4, fp5, fp6), fp8_e2m5 and the INTn lists as tables against the imported
+    reference: small inputs, every float16 pattern, the rounding-domain sweep; quant_datatype incl. its
+    float32 per-tensor branch."""
+    qw = qa.quant_weight
+    for name, arr, gs, exp in gu.more_cases(fmt):
+        w = to_dev(arr, "f16")
+        d, q, s = qw._fp_quant_meta(w, wq_bits=bits, datatype=fmt, group_size=gs)
+        assert np.array_equal(bits16(d).reshape(-1), exp["deq"].reshape(-1)), (name, gs, "deq")
+        assert np.array_equal(bits16(q).reshape(-1), exp["q"].reshape(-1)), (name, gs, "q")
+        assert np.array_equal(bits16(s.reshape(-1)), exp["scale"].reshape(-1)), (name, gs, "scale")
+        d2 = qw.quant_datatype(w, wq_bits=bits, datatype=fmt, group_size=gs)
+        assert np.array_equal(bits16(d2).reshape(-1), exp["deq_quant_datatype"].reshape(-1)), (name, gs, "qd")
+    z = gu.npz("quant_more_formats.npz")
+    w = to_dev(z[f"domain/{fmt}/in"], "f16")
+    d, q, s = qw._fp_quant_meta(w, wq_bits=bits, datatype=fmt, group_size=None)
+    assert torch.all(s == 1.0)
+    assert np.array_equal(bits16(q), z[f"domain/{fmt}/q"])
+
+
+@pytest.mark.parametrize("asym", [False, True])
+def test_golden_four_bit_int(qa, asym):
+    for name, arr, gs, exp in gu.more_cases("int4_asym.int" if asym else "int4.int"):
+        w = to_dev(arr, "f16")
+        d, q, s, zp = qa.quant_weight._int_quant_meta(w, wq_bits=4, asym=asym, group_size=gs)
+        assert np.array_equal(bits16(d).reshape(-1), exp["deq"].reshape(-1)), (name, gs)
+        assert np.array_equal(q.contiguous().view(torch.uint8).cpu().numpy().reshape(-1), exp["q"].reshape(-1)), (name, gs)
+        assert np.array_equal(bits16(s.reshape(-1)), exp["scale"].reshape(-1)), (name, gs)
+        if asym:
+            assert np.array_equal(bits16(zp.reshape(-1)), exp["zp"].reshape(-1)), (name, gs)

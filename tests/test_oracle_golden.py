@@ -63,9 +63,42 @@ def test_lut_domain_sweep(oracle, fmt):
 
 
 def test_lut_tables_closed_form(oracle):
+    """Every table format the kernels support equals the reference's value list."""
     ref = gu.load_json("lut_tables.json")
+    assert set(ref) == set(oracle.LUT_FORMATS)
     for name, (e, m, b) in oracle.LUT_FORMATS.items():
-        assert np.array_equal(oracle.build_lut(e, m, b), np.array(ref[name]))
+        assert np.array_equal(oracle.build_lut(e, m, b, name in oracle.LUT_SUBNORMAL), np.array(ref[name])), name
+
+
+@pytest.mark.parametrize("bits,fmt", gu.MORE_TABLES)
+def test_more_table_formats(oracle, bits, fmt):
+    """fp4 / fp5 / fp6 / fp8_e2m5 and the INTn lists as tables: small inputs, all float16 patterns, and the
+    rounding-domain sweep (scale == 1)."""
+    for name, w, gs, exp in gu.more_cases(fmt):
+        K, C = w.shape
+        out = oracle.quantize(w, oracle.F16, oracle.LUT, bits, gs, datatype=fmt)
+        assert np.array_equal(out["deq"], exp["deq"].reshape(K, C)), (name, gs, "deq")
+        assert np.array_equal(out["q"], exp["q"].reshape(K, C)), (name, gs, "q")
+        assert np.array_equal(out["scale"], exp["scale"].reshape(-1)), (name, gs, "scale")
+        out2 = oracle.quantize(w, oracle.F16, oracle.LUT, bits, gs, datatype=fmt, lut_f32_path=(gs == -1), want=("deq",))
+        assert np.array_equal(out2["deq"], exp["deq_quant_datatype"].reshape(K, C)), (name, gs, "quant_datatype")
+    z = gu.npz("quant_more_formats.npz")
+    w = z[f"domain/{fmt}/in"]
+    out = oracle.quantize(w, oracle.F16, oracle.LUT, bits, None, datatype=fmt)
+    assert np.all(out["scale"] == 0x3C00)
+    assert np.array_equal(out["q"], z[f"domain/{fmt}/q"].reshape(w.shape))
+
+
+@pytest.mark.parametrize("fmt", ["int4", "int4_asym"])
+def test_four_bit_int(oracle, fmt):
+    for name, w, gs, exp in gu.more_cases(fmt + ".int"):
+        K, C = w.shape
+        out = oracle.quantize(w, oracle.F16, oracle.INT_ASYM if "asym" in fmt else oracle.INT_SYM, 4, gs)
+        assert np.array_equal(out["deq"], exp["deq"].reshape(K, C)), (name, gs)
+        assert np.array_equal(out["q"], exp["q"].reshape(K, C)), (name, gs)
+        assert np.array_equal(out["scale"], exp["scale"].reshape(-1)), (name, gs)
+        if "zp" in exp:
+            assert np.array_equal(out["zp"], exp["zp"].reshape(-1)), (name, gs)
 
 
 def test_software_half_conversion(oracle):
