@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .fused import LUT_FORMATS, quantize, require_device
+from .fused import LUT_FORMATS, quantize, quantize_batch, require_device
 
 # names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
 # ValueError / AssertionError behaviour for unknown names
@@ -94,24 +94,25 @@ def _int_quant_meta(w_fp16: torch.Tensor, wq_bits: int = 4, asym: bool = False, 
     the byte is the low byte of the integer code in every case."""
     res, dev = _run(w_fp16, _lib.INT_ASYM if asym else _lib.INT_SYM, wq_bits, group_size)
     w_deq = res.deq.reshape(w_fp16.shape)
-    lead = w_fp16.shape[:-1]
-    if _is_per_tensor(group_size):
-        q = res.codes.reshape(w_fp16.shape)
-        q = q.view(torch.int8) if asym else q
-        scale = res.scale.reshape(())
-        zp = res.zero_point.reshape(()) if asym else None
-    else:
-        if _is_per_group(group_size):
-            K, C = w_fp16.shape
-            q = res.codes.reshape(K, C // group_size, group_size)
-            sshape = (K, C // group_size)
-        else:
-            q = res.codes.reshape(w_fp16.shape)
-            sshape = tuple(lead)
-        q = q if asym else q.view(torch.int8)
-        scale = res.scale.reshape(sshape)
-        zp = res.zero_point.reshape(sshape) if asym else None
+    q, scale, zp = _shape_int_meta(w_fp16.shape, asym, group_size, res.codes, res.scale, res.zero_point)
     return w_deq.to(dev), q.to(dev), scale.to(dev), (zp.to(dev) if zp is not None else None)
+
+
+def _shape_int_meta(shape, asym, group_size, codes, scale, zero_point):
+    """Views / dtypes of the integer codes and parameters as _int_quant_meta returns them (:738-775)."""
+    if _is_per_tensor(group_size):
+        q = codes.reshape(shape)
+        q = q.view(torch.int8) if asym else q
+        return q, scale.reshape(()), (zero_point.reshape(()) if asym else None)
+    if _is_per_group(group_size):
+        K, C = shape
+        q = codes.reshape(K, C // group_size, group_size)
+        sshape = (K, C // group_size)
+    else:
+        q = codes.reshape(shape)
+        sshape = tuple(shape[:-1])
+    q = q if asym else q.view(torch.int8)
+    return q, scale.reshape(sshape), (zero_point.reshape(sshape) if asym else None)
 
 
 @torch.no_grad()
@@ -120,14 +121,18 @@ def _fp_quant_meta(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Opt
     _check_table(wq_bits, datatype)
     res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype)
     w_deq = res.deq.reshape(w_fp16.shape)
-    if _is_per_tensor(group_size):
-        q, scale = res.codes.reshape(w_fp16.shape), res.scale.reshape(())
-    elif _is_per_group(group_size):
-        K, C = w_fp16.shape
-        q, scale = res.codes.reshape(K, C // group_size, group_size), res.scale.reshape(K, C // group_size)
-    else:
-        q, scale = res.codes.reshape(w_fp16.shape), res.scale.reshape(tuple(w_fp16.shape[:-1]))
+    q, scale = _shape_fp_meta(w_fp16.shape, group_size, res.codes, res.scale)
     return w_deq.to(dev), q.to(dev), scale.to(dev)
+
+
+def _shape_fp_meta(shape, group_size, codes, scale):
+    """Views of the table values and scales as _fp_quant_meta returns them (:850-872)."""
+    if _is_per_tensor(group_size):
+        return codes.reshape(shape), scale.reshape(())
+    if _is_per_group(group_size):
+        K, C = shape
+        return codes.reshape(K, C // group_size, group_size), scale.reshape(K, C // group_size)
+    return codes.reshape(shape), scale.reshape(tuple(shape[:-1]))
 
 
 class _LinearDump(nn.Linear):
@@ -135,13 +140,16 @@ class _LinearDump(nn.Linear):
     As in the reference the buffers come from quantizing the weight it is given -- which quant_model has
     already replaced by its dequantized value."""
 
-    def __init__(self, src: nn.Linear, wq_bits: int, mode: str, group_size: Optional[int]):
+    def __init__(self, src: nn.Linear, wq_bits: int, mode: str, group_size: Optional[int], meta=None):
+        """meta: (q, scale, zp | None) already computed for src.weight (quant_model's batched pass)."""
         super().__init__(src.in_features, src.out_features, bias=src.bias is not None,
                          device=src.weight.device, dtype=src.weight.dtype)
         self.weight = nn.Parameter(src.weight.detach())
         if src.bias is not None:
             self.bias = nn.Parameter(src.bias.detach())
-        if mode.startswith("int"):
+        if meta is not None:
+            q, scale, zp = meta
+        elif mode.startswith("int"):
             _, q, scale, zp = _int_quant_meta(self.weight.data, wq_bits=wq_bits, asym="asym" in mode,
                                               group_size=group_size)
         else:
@@ -168,31 +176,64 @@ def quant_model(model, wq_bits: Optional[int] = None, wq_datatype: Optional[str]
                 wq_groupsize: Optional[int] = None, _dump_int: bool = True):
     """Fake-quantize every nn.Linear weight in place, then (unless _dump_int is False) swap each Linear
     for a _LinearDump holding codes / scales / zero-points (quant_weight.py:652-706, :921-936).
-    Dispatch on the datatype string follows the reference's order."""
+    Dispatch on the datatype string follows the reference's order.
+
+    The reference loops over the layers; here the Linear weights are grouped by (shape, dtype, device) and
+    every group goes through one fused launch per 32 layers, once for the dequantized weights and once more
+    -- on the already dequantized weights, as the reference's _LinearDump does (:882-895) -- for the codes."""
     if wq_datatype is None or wq_datatype in ("fp16", "fp32"):
         print("Not applying quantization")
         return
     if wq_datatype.startswith("int"):
-        fn = quant_int_asym if "asym" in wq_datatype else quant_int
-        kind = "asymmetric" if "asym" in wq_datatype else "symmetric"
+        asym = "asym" in wq_datatype
+        fmt, table = (_lib.INT_ASYM if asym else _lib.INT_SYM), None
+        kind = "asymmetric" if asym else "symmetric"
         print(f"Applying {kind} INT quantization with bits: {wq_bits}, group size: {wq_groupsize}")
-        for name, m in _linears(model):
-            m.weight.data = fn(m.weight.data, wq_bits=wq_bits, group_size=wq_groupsize)
     elif "mx" in wq_datatype or "mixed" in wq_datatype:
         raise NotImplementedError(f"{wq_datatype}: MX / mixed-datatype search have no MI355X kernel yet")
     elif "fp" in wq_datatype:
+        _check_table(wq_bits, wq_datatype)
+        asym, fmt, table = False, _lib.LUT_FP, wq_datatype
         print(f"Applying floating-point datatype quantization with bits: {wq_bits}, group size: {wq_groupsize}")
-        for name, m in _linears(model):
-            m.weight.data = quant_datatype(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype,
-                                           group_size=wq_groupsize)
     else:
         raise ValueError(f"Unsupported datatype {wq_datatype}")
 
+    linears = _linears(model)
+    groups = {}
+    for name, m in linears:
+        w = m.weight.data
+        if _is_per_group(wq_groupsize):
+            K, C = w.size()
+        groups.setdefault((tuple(w.shape), w.dtype, w.device), []).append((name, m))
+    meta = {}
+    for (shape, _, dev), members in groups.items():
+        rows = 1
+        for d in shape[:-1]:
+            rows *= d
+        stack = [require_device(m.weight.data).reshape(rows, shape[-1]) for _, m in members]
+        # 1) dequantized weights (quant_datatype's per-tensor branch runs in float32, :562-575)
+        res = quantize_batch(stack, fmt, wq_bits, wq_groupsize, table, codes=False, scale=False,
+                             f32_math=(fmt == _lib.LUT_FP and _is_per_tensor(wq_groupsize)))
+        for i, (_, m) in enumerate(members):
+            m.weight.data = res.deq[i].reshape(shape).to(dev)
+        if not _dump_int:
+            continue
+        # 2) codes / scales / zero-points of the DEQUANTIZED weights
+        stack = [require_device(m.weight.data).reshape(rows, shape[-1]) for _, m in members]
+        res = quantize_batch(stack, fmt, wq_bits, wq_groupsize, table, deq=False)
+        for i, (name, _) in enumerate(members):
+            if fmt == _lib.LUT_FP:
+                q, scale = _shape_fp_meta(shape, wq_groupsize, res.codes[i], res.scale[i])
+                zp = None
+            else:
+                q, scale, zp = _shape_int_meta(shape, asym, wq_groupsize, res.codes[i], res.scale[i],
+                                               res.zero_point[i] if asym else None)
+            meta[name] = (q.to(dev), scale.to(dev), zp.to(dev) if zp is not None else None)
     if not _dump_int:
         return
-    for name, mod in _linears(model):
+    for name, mod in linears:
         parent, attr = _find_parent(model, name)
-        setattr(parent, attr, _LinearDump(mod, wq_bits, wq_datatype, wq_groupsize))
+        setattr(parent, attr, _LinearDump(mod, wq_bits, wq_datatype, wq_groupsize, meta=meta[name]))
 
 
 def _find_parent(root: nn.Module, target_name: str):

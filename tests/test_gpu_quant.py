@@ -358,3 +358,35 @@ def test_golden_four_bit_int(qa, asym):
         assert np.array_equal(bits16(s.reshape(-1)), exp["scale"].reshape(-1)), (name, gs)
         if asym:
             assert np.array_equal(bits16(zp.reshape(-1)), exp["zp"].reshape(-1)), (name, gs)
+
+
+def test_quant_model_batched_equals_per_layer(qa):
+    """quant_model groups the Linear layers by shape and runs one fused launch per group; weights and buffers
+    must equal what the per-layer functions give (codes come from the already dequantized weight, as in the
+    reference's _LinearDump)."""
+    import torch.nn as nn
+    qw = qa.quant_weight
+    for datatype, bits, gs in (("int8", 8, None), ("int4_asym", 4, 64), ("fp8_e4m3", 8, 128), ("fp4", 4, -1),
+                               ("int8_asym", 8, -1)):
+        torch.manual_seed(1)
+        layers = [nn.Linear(256, 128), nn.Linear(128, 256), nn.Linear(256, 128, bias=False), nn.Linear(256, 128),
+                  nn.Linear(128, 256)]
+        model = nn.Sequential(*layers).half().cuda()
+        orig = [m.weight.data.clone() for m in model]
+        qw.quant_model(model, bits, datatype, gs)
+        for i, m in enumerate(model):
+            if datatype.startswith("int"):
+                asym = "asym" in datatype
+                d = (qw.quant_int_asym if asym else qw.quant_int)(orig[i], bits, gs)
+                _, q, s, zp = qw._int_quant_meta(d, bits, asym, gs)
+            else:
+                d = qw.quant_datatype(orig[i], bits, datatype, gs)
+                _, q, s = qw._fp_quant_meta(d, bits, datatype, gs)
+                zp = None
+            assert torch.equal(m.weight.data.view(torch.int16), d.view(torch.int16)), (datatype, i, "weight")
+            assert torch.equal(m.weight_q, q.to(torch.float16)) and m.weight_q.shape == q.shape, (datatype, i, "q")
+            assert torch.equal(m.weight_scale.view(torch.int16), s.to(torch.float16).view(torch.int16)), (datatype, i)
+            if zp is not None:
+                assert torch.equal(m.weight_zp.view(torch.int16), zp.view(torch.int16)), (datatype, i, "zp")
+            else:
+                assert not hasattr(m, "weight_zp")
