@@ -125,6 +125,31 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     return out
 
 
+def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", device=None) -> List[Dict]:
+    """main() of MSE&P99/quant_error_multi_weight.py:119-164 on two ONNX files, without the `onnx` package and
+    with the arithmetic on the device: for every MatMul / Gemm weight of the baseline model that the quantized
+    model also holds, float32 cast, tensor MSE, per-vector MSE list (form="multi": columns / column blocks as
+    that script; form="single": rows / (row, group) as quant_error_single_weight.py), its mean and P99.
+    Returns the CSV rows (write them with write_csv)."""
+    from .error_metrics import compute_errors
+    from .onnx_io import OnnxWeights
+    grouping, dtype, bits, gs = parse_quant_config(quant_model)
+    rows = []
+    with OnnxWeights(baseline_model) as base, OnnxWeights(quant_model) as quant:
+        wanted = set(base.compute_weights())
+        have = set(quant.names())
+        for name in base.names():
+            if name not in wanted or name not in have:
+                continue
+            a = base.tensor(name, device).float()   # proto_to_array: everything becomes float32
+            b = quant.tensor(name, device).float()
+            stats = compute_errors(a, b, grouping, gs, form=form)
+            rows.append({"initializer": name, "datatype": dtype, "granularity": grouping, "bits": bits or "",
+                         "mse_tensor": stats["mse_tensor"], "mse_rep": stats.get("mse_rep", ""),
+                         "mse_p99": stats.get("mse_p99", "")})
+    return rows
+
+
 def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size) -> List[Dict]:
     """Device records -> the CSV rows of quant_error_multi_weight.py:142-151 (one host copy)."""
     host = records.cpu().tolist()

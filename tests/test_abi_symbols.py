@@ -1,4 +1,4 @@
-"""CPU: libmq.so loads and exports every function include/mq.h declares (no compute calls here)."""
+"""CPU: libmq.so loads and exports every function include/*.h declares (no compute calls here)."""
 import ctypes
 import os
 import re
@@ -7,15 +7,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def declared_functions():
-    text = open(os.path.join(ROOT, "include", "mq.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("mq.h", "mq_onnx.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(mq_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_header_symbols():
     from quantization_amd import _lib
     names = declared_functions()
-    assert "mq_quantize" in names and "mq_version" in names
+    assert "mq_quantize" in names and "mq_version" in names and "mq_onnx_open" in names
     L = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(L, n), f"libmq.so does not export {n}"

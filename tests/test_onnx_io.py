@@ -1,0 +1,91 @@
+"""The ONNX initializer reader (include/mq_onnx.h) against files written by tests/onnx_writer.py.  No `onnx`
+package is available, so the file format follows onnx.proto as published; host-only code, runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from onnx_writer import write_model
+
+
+@pytest.fixture(scope="module")
+def io():
+    from quantization_amd import onnx_io
+    return onnx_io
+
+
+def _model(tmp, sub, scale=1.0, seed=0):
+    rng = np.random.default_rng(seed)
+    inits = {
+        "fc1.weight": (rng.standard_normal((64, 48)) * 0.02 * scale).astype(np.float16),      # Gemm weight, external
+        "attn.q_proj.weight": (rng.standard_normal((32, 32)) * 0.02 * scale).astype(np.float16),  # via Transpose
+        "small.weight": (rng.standard_normal((4, 8)) * scale).astype(np.float16),              # MatMul weight, inline
+        "fc1.bias": rng.standard_normal(64).astype(np.float16),                                # not a weight
+        "embed.weight": rng.standard_normal((100, 16)).astype(np.float32),                     # used by Gather only
+        "shape_const": np.array([1, -1, 32], np.int64),
+        "fc1.weight_q": rng.integers(0, 255, (64, 48)).astype(np.uint8),
+    }
+    nodes = [("Gather", ["embed.weight", "ids"], ["h0"]),
+             ("Gemm", ["h0", "fc1.weight", "fc1.bias"], ["h1"]),
+             ("Transpose", ["attn.q_proj.weight"], ["q_t"]),
+             ("MatMul", ["h1", "q_t"], ["h2"]),
+             ("Reshape", ["h2", "shape_const"], ["h3"]),
+             ("MatMul", ["h3", "small.weight"], ["h4"]),
+             ("MatMul", ["h4", "h0"], ["h5"])]
+    path = os.path.join(tmp, sub, "model.onnx")
+    write_model(path, inits, nodes)
+    return path, inits
+
+
+def test_reader_finds_weights_and_bytes(io, tmp_path):
+    path, inits = _model(str(tmp_path), "fp16")
+    assert os.path.exists(path + ".data")
+    with io.OnnxWeights(path) as m:
+        assert m.names() == list(inits)
+        assert m.compute_weights() == ["fc1.weight", "attn.q_proj.weight", "small.weight"]
+        for name, arr in inits.items():
+            got = m.array(name)
+            assert got.dtype == arr.dtype and got.shape == arr.shape
+            assert got.tobytes() == arr.tobytes(), name
+
+
+def test_reader_errors(io, tmp_path):
+    with pytest.raises(OSError):
+        io.OnnxWeights(str(tmp_path / "missing.onnx"))
+    bad = tmp_path / "bad.onnx"
+    bad.write_bytes(b"\x3a\xff\xff\xff\xff\x0f")  # graph field whose length runs past the end of the file
+    with pytest.raises(OSError):
+        io.OnnxWeights(str(bad))
+    path, _ = _model(str(tmp_path), "trunc")
+    with open(path + ".data", "r+b") as f:
+        f.truncate(100)
+    with pytest.raises(OSError):
+        io.OnnxWeights(path)
+
+
+@pytest.mark.gpu
+def test_compare_onnx_report(io, tmp_path, oracle):
+    """Two exported models -> the rows of quant_error_multi_weight.py, against the numpy restatement."""
+    import torch
+    import quantization_amd as qa
+    from quantization_amd import report
+    base_path, inits = _model(str(tmp_path), os.path.join("onnx_graph", "m", "baseline", "fp16"))
+    qinits = dict(inits)
+    for name in ("fc1.weight", "attn.q_proj.weight"):
+        w = torch.from_numpy(inits[name]).cuda()
+        qinits[name] = qa.quant_weight.quant_int_asym(w, 8, 16).cpu().numpy()
+    del qinits["small.weight"]          # a weight the quantized model does not hold is skipped
+    qpath = os.path.join(str(tmp_path), "onnx_graph", "m", "per-group", "int8_asym", "w_8_gs_16", "model.onnx")
+    write_model(qpath, qinits, [])
+    rows = report.compare_onnx(base_path, qpath)
+    assert [r["initializer"] for r in rows] == ["fc1.weight", "attn.q_proj.weight"]
+    for r in rows:
+        a = inits[r["initializer"]].astype(np.float32)
+        b = qinits[r["initializer"]].astype(np.float32)
+        want = oracle.compute_errors_multi(a, b, "per-group", 16)
+        assert r["datatype"] == "int8_asym" and r["granularity"] == "per-group" and r["bits"] == 8
+        for k in ("mse_tensor", "mse_rep", "mse_p99"):
+            assert abs(r[k] - want[k]) <= 1e-6 * abs(want[k]), (r["initializer"], k)
+    out = tmp_path / "report.csv"
+    report.write_csv(rows, str(out))
+    assert out.read_text().splitlines()[0] == "initializer,datatype,granularity,bits,mse_tensor,mse_rep,mse_p99"
