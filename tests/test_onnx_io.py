@@ -89,3 +89,39 @@ def test_compare_onnx_report(io, tmp_path, oracle):
     out = tmp_path / "report.csv"
     report.write_csv(rows, str(out))
     assert out.read_text().splitlines()[0] == "initializer,datatype,granularity,bits,mse_tensor,mse_rep,mse_p99"
+
+
+def test_reader_survives_corrupt_files_under_sanitizers(tmp_path):
+    """The reader parses files it did not write: build it with AddressSanitizer + UBSan (host code only) and
+    feed it truncations and random byte flips of a valid model."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "onnx_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-static-libasan", "-static-libubsan",
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "tools", "onnx_fuzz.cpp"),
+                           os.path.join(root, "quantization_amd", "csrc", "mq_onnx.cpp"), "-o", exe])
+    path, _ = _model(str(tmp_path), "seed")
+    good = open(path, "rb").read()
+    rng = np.random.default_rng(0)
+    files = [path]
+    for i in range(150):
+        d = tmp_path / f"mut{i}"
+        d.mkdir()
+        shutil.copy(path + ".data", d / "model.onnx.data")
+        b = bytearray(good)
+        if i % 3 == 0:
+            b = b[: int(rng.integers(0, len(b)))]
+        else:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        (d / "model.onnx").write_bytes(bytes(b))
+        if i % 10 == 0:
+            with open(d / "model.onnx.data", "r+b") as f:
+                f.truncate(int(rng.integers(0, 4000)))
+        files.append(str(d / "model.onnx"))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1")
+    r = subprocess.run([exe] + files, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("opened ")
