@@ -120,7 +120,9 @@ int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype
  * elwise_error/onnx_error_cli.py:113-114) for every tensor, with the selection fed from the quantize pass
  * itself: a sampling pass over 1/32 of the weight brackets the wanted ranks, the full pass counts the errors
  * below the bracket and histograms those inside it while they are in registers, so the error array is not
- * read back (the two-pass selection over it runs only when the bracket misses).  Every item must request
+ * read back (the two-pass selection over it runs only when the bracket misses).  This holds for segments of
+ * up to 512 elements (groups); per-channel / per-tensor shapes, small tensors and quantiles at the very ends
+ * quantize first and select from the stored error array.  Every item must request
  * the float32 abs_err array (16-byte aligned).  p99: device array of `count` floats.
  */
 size_t mq_quantize_p99_batch_workspace_bytes(int32_t count, int64_t rows, int64_t cols, const mq_quant_cfg* cfg);

@@ -639,27 +639,35 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int64_t tiles = (p.nseg + (int64_t)SPW * NV - 1) / ((int64_t)SPW * NV);
-  // sampling pass of a selection: one pseudo-randomly chosen tile of every 32
-  // (of the FULL tiles, so that the samples are dense: tile t of the sample holds SPW * NV whole segments)
+  // sampling pass of a selection: ONE of the NV vector slots (SPW whole segments, 512 consecutive elements
+  // when the teams are full) of one pseudo-randomly chosen tile out of every 8 FULL tiles, so that the
+  // samples are dense and come from 4 x more places than whole sampled tiles would
   constexpr bool samp = SEL == SEL_FEED_SAMPLE;
-  const int64_t steps = samp ? (p.nseg / ((int64_t)SPW * NV)) / 32 : tiles;
-  auto tile_of = [&](int64_t t) { return samp ? t * 32 + (int64_t)sample_line((uint32_t)t) : t; };
+  static_assert(NV == 4, "the sampling pattern assumes 4 vector slots per tile");
+  const int64_t steps = samp ? (p.nseg / ((int64_t)SPW * NV)) / 8 : tiles;
+  auto tile_of = [&](int64_t t) { return samp ? t * 8 + (int64_t)(sample_line((uint32_t)t) & 7u) : t; };
+  auto slot_of = [&](int64_t t) { return (int)(sample_line((uint32_t)t) >> 3); };
   const bool lane_in_seg = tl < p.vecs_per_seg;
   // Software pipeline: the next tile's loads are issued before the current tile is computed, so a wave
   // keeps 2 x NV KiB in flight.
   u32x4 nxt[NV];
-  auto issue = [&](int64_t tile, u32x4* dst) {
+  auto issue = [&](int64_t t, u32x4* dst) {
+    const int64_t tile = tile_of(t);
+    const int js = samp ? slot_of(t) : 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       int64_t sg = (tile * NV + j) * SPW + team;
-      dst[j] = (lane_in_seg && sg < p.nseg) ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
-                                            : u32x4{0, 0, 0, 0};
+      dst[j] = (lane_in_seg && sg < p.nseg && (!samp || j == js))
+                   ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
+                   : u32x4{0, 0, 0, 0};
     }
   };
-  if (gw < steps) issue(tile_of(gw), nxt);
+  if (gw < steps) issue(gw, nxt);
   for (int64_t t = gw; t < steps; t += nwaves) {
     const int64_t tile = tile_of(t);
-    if constexpr (SEL == SEL_FEED_SAMPLE) acc.sel.sample_shift = (t - tile) * ((int64_t)SPW * NV) * p.L;
+    const int js = samp ? slot_of(t) : 0;
+    // dense sample index of an element = its offset inside the sampled slot + t * (slot size)
+    if constexpr (samp) acc.sel.sample_shift = (t - (tile * NV + js)) * (int64_t)SPW * p.L;
     u32x4 raw[NV];
     bool valid[NV];
     int64_t seg[NV];
@@ -667,9 +675,9 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
     for (int j = 0; j < NV; ++j) {
       raw[j] = raw_to_f16(nxt[j], p.in_dtype);
       seg[j] = (tile * NV + j) * SPW + team;
-      valid[j] = lane_in_seg && seg[j] < p.nseg;
+      valid[j] = lane_in_seg && seg[j] < p.nseg && (!samp || j == js);
     }
-    if (t + nwaves < steps) issue(tile_of(t + nwaves), nxt);
+    if (t + nwaves < steps) issue(t + nwaves, nxt);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       SegP sp;
@@ -1319,13 +1327,14 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     *sampled = 0;
     if (scope == SC_SUBWAVE) {  // tiles of (64 / team) * 4 segments, one of every 32 tiles
       const int64_t per_tile = (int64_t)(64 >> team_log2) * 4;
-      *sampled = ((p.nseg / per_tile) / 32) * per_tile * p.L;  // full tiles only
-    } else if (scope == SC_WAVE || scope == SC_BLOCK) {  // one of every 32 segments
-      *sampled = (p.nseg / 32) * p.L;
+      *sampled = ((p.nseg / per_tile) / 8) * (per_tile / 4) * p.L;  // one slot of every 8 full tiles
     }
+    // Rows (SC_WAVE / SC_BLOCK) are not sampled: whole sampled rows are too few, too correlated clusters for
+    // the bracket to hold, and a row cannot be quantized in part before its maximum is known.  Those shapes
+    // select from the stored error array, whose samples are single 256-byte lines.
     return MQ_OK;
   }
-  if (sel_mode != SEL_FEED_OFF && scope != SC_SUBWAVE && scope != SC_WAVE && scope != SC_BLOCK) return MQ_ERR_UNSUPPORTED;
+  if (sel_mode != SEL_FEED_OFF && scope != SC_SUBWAVE) return MQ_ERR_UNSUPPORTED;
   const size_t lds = sel_mode == SEL_FEED_COUNT ? (size_t)2 * SEL_FEED_HASH * sizeof(uint32_t) : 0;
 
   if (scope == SC_TENSOR) {

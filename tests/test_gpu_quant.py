@@ -304,23 +304,24 @@ def test_fused_p99_matches_numpy_on_the_dump():
 
 
 def test_fused_p99_survives_a_misleading_sample():
-    """The sampling pass looks at one tile of every 32 (team kernels: (64 / team) * 4 segments per tile, tile
-    t * 32 + top 5 bits of t * 0x9E3779B1).  Zero weights in exactly those tiles make the sample say 'all
-    errors are 0'; the result must still be numpy's."""
+    """The sampling pass of the team kernels looks at one vector slot -- (64 / team) segments -- of one tile
+    (4 slots) out of every 8 tiles: h = top 5 bits of t * 0x9E3779B1, tile t * 8 + (h & 7), slot h >> 3.  Zero
+    weights in exactly those slots make the sample say 'all errors are 0'; the result must still be numpy's."""
     import numpy as np
     import torch
     from quantization_amd import _lib
     from quantization_amd.fused import quantize_batch
     g = torch.Generator(device="cuda").manual_seed(6)
-    rows, cols, gs = 2048, 2048, 64          # team of 8 lanes: 8 segments x 4 = 32 segments per tile
+    rows, cols, gs = 2048, 2048, 64          # team of 8 lanes: 8 segments per slot, 32 per tile
     w = (torch.randn(1, rows, cols, generator=g, device="cuda") * 0.02).half()
-    seg_per_tile = (64 // (gs // 8)) * 4
+    seg_per_slot = 64 // (gs // 8)
     nseg = rows * cols // gs
-    tiles = (nseg + seg_per_tile - 1) // seg_per_tile
-    t = np.arange(tiles // 32, dtype=np.uint64)
-    tile = t * np.uint64(32) + (((t * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(27))
-    flat = w.view(-1, seg_per_tile * gs)
-    flat[torch.from_numpy(tile.astype(np.int64)).cuda()] = 0
+    tiles = nseg // (seg_per_slot * 4)
+    t = np.arange(tiles // 8, dtype=np.uint64)
+    h = ((t * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(27)
+    slot = (t * np.uint64(8) + (h & np.uint64(7))) * np.uint64(4) + (h >> np.uint64(3))
+    flat = w.view(-1, seg_per_slot * gs)
+    flat[torch.from_numpy(slot.astype(np.int64)).cuda()] = 0
     a = quantize_batch(w, _lib.INT_ASYM, 8, gs, None, abs_err=torch.float32, p99=99)
     want = np.float32(np.percentile(a.abs_err.cpu().numpy().ravel(), 99))
     assert a.abs_p99.cpu().numpy().tobytes() == np.array([want], np.float32).tobytes()
