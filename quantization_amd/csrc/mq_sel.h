@@ -10,7 +10,8 @@
 #define SEL_DIGIT_BINS 65536
 #define SEL_HASH 2048
 #define SEL_MAX_BATCH 64
-#define SEL_BR_BINS 16       // widest bracket, in level-0 bins
+#define SEL_BR_BINS 16       // bracket histogram: 16 x 65536 entries
+#define SEL_BR_MAX_BINS 256  // widest bracket in level-0 bins (then 16 bit patterns share a histogram entry)
 #define SEL_BR_HASH 4096
 #define SEL_CHUNK_LINES 32   // one 256-byte line of every 32 is sampled
 #define SEL_BR_MIN_N (1 << 21)
@@ -31,9 +32,15 @@ struct SelLevel {  // histograms of one level >= 1, for the two tracked ranks
 struct SelWs {
   SelState st;
   uint32_t br_lo, br_nb;     // bracket: first level-0 bin, number of bins (0: none)
-  uint32_t ok, pad0;         // 1: the bracket pass produced the result
+  uint32_t ok;               // 1: the result is final; 2: the bracket located both ranks up to 2^br_shift
+                             //    bit patterns and the refining pass over the stored array must finish them
+  uint32_t br_shift;         // bit patterns per bracket-histogram entry = 2^br_shift (0 for <= 16 bins)
   unsigned long long below;  // exact number of elements under the bracket
-  uint32_t pad[48];
+  uint32_t ref_base[2];      // ok == 2: first bit pattern of the entry holding rank r ...
+  uint32_t pad1[2];
+  unsigned long long ref_rank[2];  // ... and the rank inside that entry
+  uint32_t refine[2][16];    // counts per bit pattern inside those entries (filled by the refining pass)
+  uint32_t pad[8];
   uint32_t top_coarse[SEL_TOP_BINS / 256];
   uint32_t top[SEL_TOP_BINS];
   SelLevel lvl[3];  // cleared once per selection, only as many as the dtype needs
@@ -75,7 +82,7 @@ struct SelFeed {
   lds_u32* hkey;  // LDS [SEL_FEED_HASH]: key + 1, 0 = empty
   lds_u32* hcnt;  // LDS [SEL_FEED_HASH]
   SelWs* ws;
-  uint32_t lo, nb;  // bracket (count mode)
+  uint32_t lo, nb, shift;  // bracket (count mode)
   uint32_t below;   // this lane's count of values under the bracket
   int mode;
   uint16_t* samples;     // sample mode: where this array's samples go
@@ -96,11 +103,13 @@ __device__ __forceinline__ void sel_feed_init(SelFeed& f, SelWs* ws, uint32_t* l
   f.hcnt = (lds_u32*)lds + SEL_FEED_HASH;
   f.lo = 0;
   f.nb = 0;
+  f.shift = 0;
   f.below = 0;
   if (mode == SEL_FEED_COUNT) {
     for (int i = threadIdx.x; i < 2 * SEL_FEED_HASH; i += blockDim.x) lds[i] = 0;
     f.lo = ws->br_lo;
     f.nb = ws->br_nb;
+    f.shift = ws->br_shift;
     __syncthreads();
   }
 }
@@ -164,7 +173,7 @@ __device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0
                    p3 = (i & 1) ? a[7] : a[6];
     const uint32_t q0 = (i & 2) ? p1 : p0, q1 = (i & 2) ? p3 : p2;
     const uint32_t bits = (i & 4) ? q1 : q0;
-    sel_feed_add(f, bits - lo_bits, f.ws->br_fine, f.ws->br_coarse);
+    sel_feed_add(f, (bits - lo_bits) >> f.shift, f.ws->br_fine, f.ws->br_coarse);
   }
 }
 
@@ -204,7 +213,8 @@ __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < f.nb * 256; i += blockDim.x)
+  const uint32_t ncoarse = ((f.nb << 16) >> f.shift) >> 8;  // <= SEL_BR_BINS * 256
+  for (uint32_t i = threadIdx.x; i < ncoarse; i += blockDim.x)
     if (lco[i]) atomicAdd(&f.ws->br_coarse[i], lco[i]);
 }
 static_assert(2 * SEL_FEED_HASH >= SEL_BR_BINS * 256, "coarse overlay fits the table");

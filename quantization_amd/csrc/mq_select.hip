@@ -73,8 +73,8 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
   extern __shared__ uint32_t lh[];
   const T* x = static_cast<const T*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
-  if (guard && ws->ok) return;
   const int64_t n = b.n[blockIdx.y];
+  if (guard && ws->ok) return;
   for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte load
@@ -157,7 +157,33 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
   __shared__ uint64_t sh_rank;
   __shared__ SelState st;
   SelWs* ws = batch_ws(b, blockIdx.x);
-  if (guard && ws->ok) return;
+  if (guard) {
+    const uint32_t ok = ws->ok;
+    if (ok == 1) return;
+    if (ok == 2) {  // a refined selection (float32): the last level's scan walks the <= 16 patterns of each
+      if (fin.dtype < 0) return;  // located entry, after the matched-digit kernel has counted them
+      if (threadIdx.x == 0) {
+        uint32_t bits[2];
+        for (int r = 0; r < 2; ++r) {
+          uint64_t rest = ws->ref_rank[r];
+          uint32_t d = 0;
+          const uint32_t width = 1u << ws->br_shift;
+          while (d + 1 < width && rest >= ws->refine[r][d]) { rest -= ws->refine[r][d]; ++d; }
+          bits[r] = ws->ref_base[r] + d;
+        }
+        float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
+        float g = (float)rk.gamma[blockIdx.x], diff = c - a;
+        float v = a + diff * g;
+        if (g >= 0.5f) v = c - diff * (1.0f - g);
+        if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
+        if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+        ws->st.prefix[0] = (uint64_t)bits[0] << 32;
+        ws->st.prefix[1] = (uint64_t)bits[1] << 32;
+        ws->ok = 1;
+      }
+      return;
+    }
+  }
   if (threadIdx.x == 0) {
     if (level == 0) {  // the ranks arrive with the first scan
       SelState s0 = {};
@@ -214,9 +240,39 @@ __global__ __launch_bounds__(256) void k_sel_hist_digit(const SelBatch b, int le
   __shared__ uint32_t hcnt[2][SEL_HASH];
   const T* x = static_cast<const T*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
-  if (guard && ws->ok) return;
-  SelLevel* lv = &ws->lvl[level - 1];
   const int64_t n = b.n[blockIdx.y];
+  if (guard) {
+    const uint32_t ok = ws->ok;
+    if (ok == 1) return;
+    if (ok == 2) {  // refining pass: count the bit patterns inside the two located histogram entries
+      if constexpr (sizeof(T) == 4) {
+        const uint32_t base0 = ws->ref_base[0], base1 = ws->ref_base[1], width = 1u << ws->br_shift;
+        const uint32_t* xs = static_cast<const uint32_t*>(b.x[blockIdx.y]);
+        const int64_t nvec = n / 4;
+        const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+        auto put = [&](uint32_t bits) {
+          bits &= 0x7fffffffu;
+          if (bits - base0 < width) atomicAdd(&ws->refine[0][bits - base0], 1u);
+          if (bits - base1 < width) atomicAdd(&ws->refine[1][bits - base1], 1u);
+        };
+        for (int64_t v0 = t0; v0 < nvec; v0 += 4 * step) {  // 4 loads in flight per lane
+          u32x4 raw[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int64_t v = v0 + u * step;
+            raw[u] = v < nvec ? reinterpret_cast<const u32x4*>(xs)[v] : u32x4{~0u, ~0u, ~0u, ~0u};
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) put(raw[u][i]);
+        }
+        for (int64_t i = nvec * 4 + t0; i < n; i += step) put(xs[i]);
+      }
+      return;
+    }
+  }
+  SelLevel* lv = &ws->lvl[level - 1];
   for (int i = threadIdx.x; i < 2 * SEL_HASH; i += blockDim.x) { (&hkey[0][0])[i] = 0; (&hcnt[0][0])[i] = 0; }
   __syncthreads();
   const int shift = 48 - 16 * level;
@@ -363,16 +419,23 @@ __global__ __launch_bounds__(256) void k_sel_scan_sample(const SelBatch b, const
   locate(ws->samp_coarse, ws->samp, SEL_TOP_BINS / 256, r_hi, wsum, &sh_bin, &sh_rank);
   const uint32_t hi = sh_bin;
   if (threadIdx.x == 0) {
-    const bool usable = hi >= lo && hi - lo < SEL_BR_BINS;
+    // up to 16 bins: one histogram entry per bit pattern; up to 256 bins: 2^shift patterns per entry, and a
+    // refining pass over the stored array finishes the job
+    const bool usable = hi >= lo && hi - lo < SEL_BR_MAX_BINS;
+    const uint32_t nb = usable ? hi - lo + 1 : 0;
+    uint32_t shift = 0;
+    while (((nb << 16) >> shift) > (uint32_t)SEL_BR_BINS * 65536u) ++shift;
     ws->br_lo = lo;
-    ws->br_nb = usable ? hi - lo + 1 : 0;
+    ws->br_nb = nb;
+    ws->br_shift = shift;
   }
 }
 
 // Clears the part of the bracket histogram that the bracket found by the sample scan will use.
 __global__ __launch_bounds__(256) void k_sel_clear_bracket(const SelBatch b) {
   SelWs* ws = batch_ws(b, blockIdx.y);
-  const uint32_t nbins = ws->br_nb;
+  const uint32_t entries = (ws->br_nb << 16) >> ws->br_shift;
+  const uint32_t nbins = (entries + 65535u) >> 16;  // whole chunks of 65536 entries, as the scan reads them
   const u32x4 z = {0, 0, 0, 0};
   u32x4* coarse = reinterpret_cast<u32x4*>(ws->br_coarse);
   u32x4* fine = reinterpret_cast<u32x4*>(ws->br_fine);
@@ -386,7 +449,7 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
   __shared__ uint32_t wcnt[4];
   const u32x4* x = static_cast<const u32x4*>(b.x[blockIdx.y]);
   SelWs* ws = batch_ws(b, blockIdx.y);
-  const uint32_t lo = ws->br_lo, nbins = ws->br_nb;
+  const uint32_t lo = ws->br_lo, nbins = ws->br_nb, shift = ws->br_shift;
   if (nbins == 0) return;
   for (int i = threadIdx.x; i < SEL_BR_HASH; i += blockDim.x) { hkey[i] = 0; hcnt[i] = 0; }
   __syncthreads();
@@ -396,7 +459,7 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
     const uint32_t t = (bits >> 16) - lo;  // wraps for bins under the bracket
     below += (bits >> 16) < lo ? 1u : 0u;
     if (t < nbins) {
-      const uint32_t key = (t << 16) | (bits & 0xffffu);
+      const uint32_t key = ((t << 16) | (bits & 0xffffu)) >> shift;
       uint32_t h = (key * 2654435761u) >> 20;  // 12 bits
       for (int probe = 0; probe < 64; ++probe) {
         uint32_t old = hkey[h];  // plain read first: repeated values skip the compare-and-swap
@@ -410,18 +473,21 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
   };
   const int64_t n = b.n[blockIdx.y], nvec = n / 4;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
-  int64_t v = t0;
-  for (; v + step < nvec; v += 2 * step) {  // two loads in flight
-    u32x4 r0 = x[v], r1 = x[v + step];
+  for (int64_t v0 = t0; v0 < nvec; v0 += 4 * step) {  // four loads in flight per lane
+    u32x4 raw[4];
+    bool have[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) put(r0[i]);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t v = v0 + u * step;
+      have[u] = v < nvec;
+      raw[u] = have[u] ? x[v] : u32x4{0, 0, 0, 0};
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) put(r1[i]);
-  }
-  for (; v < nvec; v += step) {
-    u32x4 r0 = x[v];
+    for (int u = 0; u < 4; ++u) {
+      if (!have[u]) break;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) put(r0[i]);
+      for (int i = 0; i < 4; ++i) put(raw[u][i]);
+    }
   }
   const uint32_t* xs = static_cast<const uint32_t*>(b.x[blockIdx.y]);
   for (int64_t i = nvec * 4 + t0; i < n; i += step) put(xs[i]);
@@ -443,13 +509,14 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
     }
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < nbins * 256; i += blockDim.x) {
+  for (uint32_t i = threadIdx.x; i < ((nbins << 16) >> shift) >> 8; i += blockDim.x) {
     const uint32_t c = lcoarse[i];
     if (c) atomicAdd(&ws->br_coarse[i], c);
   }
 }
 
-// Both ranks inside the bracket -> exact values, interpolation, ok = 1.
+// Both ranks inside the bracket -> exact values, interpolation, ok = 1; with a coarse bracket histogram
+// (br_shift > 0) -> the entries holding them, ok = 2 (the refining pass finishes).
 __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, const SelRanks rk, FinishArgs fin) {
   const uint64_t k0 = rk.k0[blockIdx.x], k1 = rk.k1[blockIdx.x];
   __shared__ uint64_t wsum[4];
@@ -457,30 +524,42 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
   __shared__ uint64_t sh_rank;
   __shared__ uint64_t tot[SEL_BR_BINS + 1];
   SelWs* ws = batch_ws(b, blockIdx.x);
-  const uint32_t nbins = ws->br_nb;
-  if (nbins == 0) return;
+  if (ws->br_nb == 0) return;
+  const uint32_t shift = ws->br_shift;
+  const uint32_t entries = (ws->br_nb << 16) >> shift;
+  const uint32_t nchunks = (entries + 65535u) >> 16;  // chunks of 65536 histogram entries
   if (threadIdx.x == 0) { sh_bin = 0; sh_rank = 0; tot[0] = 0; }
-  for (uint32_t j = 0; j < nbins; ++j) {  // elements per bracket bin
+  for (uint32_t j = 0; j < nchunks; ++j) {  // elements per chunk
     uint64_t c = ws->br_coarse[j * 256 + threadIdx.x];
     uint64_t before = block_excl_scan(c, wsum);
     if (threadIdx.x == 255) tot[j + 1] = before + c;
     __syncthreads();
   }
   if (threadIdx.x == 0)
-    for (uint32_t j = 0; j < nbins; ++j) tot[j + 1] += tot[j];
+    for (uint32_t j = 0; j < nchunks; ++j) tot[j + 1] += tot[j];
   __syncthreads();
-  const uint64_t below = ws->below, inside = tot[nbins];
+  const uint64_t below = ws->below, inside = tot[nchunks];
   if (k0 < below || k1 >= below + inside) return;  // not resolved here: the exact route runs
   uint32_t bits[2];
+  uint64_t rest[2];
   for (int r = 0; r < 2; ++r) {
     const uint64_t rk = (r ? k1 : k0) - below;
     uint32_t j = 0;
-    while (j + 1 < nbins && rk >= tot[j + 1]) ++j;
+    while (j + 1 < nchunks && rk >= tot[j + 1]) ++j;
     locate(ws->br_coarse + j * 256, ws->br_fine + j * 65536, 256, rk - tot[j], wsum, &sh_bin, &sh_rank);
-    bits[r] = ((ws->br_lo + j) << 16) | sh_bin;
+    bits[r] = (ws->br_lo << 16) + (((j << 16) | sh_bin) << shift);  // first bit pattern of the entry
+    rest[r] = sh_rank;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    if (shift) {
+      ws->ref_base[0] = bits[0];
+      ws->ref_base[1] = bits[1];
+      ws->ref_rank[0] = rest[0];
+      ws->ref_rank[1] = rest[1];
+      ws->ok = 2;
+      return;
+    }
     float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
     float g = (float)rk.gamma[blockIdx.x], diff = c - a;
     float v = a + diff * g;
