@@ -21,10 +21,18 @@
 // tests/test_division_shortcut.py); segments outside that domain (inf / NaN, or |v/s| >= 500) take the
 // per-element slow path, which follows the contract literally.
 // This file must be compiled with -ffp-contract=off and without fast-math.
+//
+// The file is compiled four times (Makefile): MQ_PART 0 holds the host side and the format-independent
+// kernels; MQ_PART 1 / 2 / 3 hold the kernel instantiations of one format each (symmetric INT, asymmetric INT,
+// value tables) behind mq_launch_fmt<N>(), so that a clean build runs in parallel.
 #include <stdlib.h>
 
 #include "mq_common.h"
 #include "mq_sel.h"
+
+#ifndef MQ_PART
+#error "compile with -DMQ_PART=0..3 (see Makefile)"
+#endif
 
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
 
@@ -851,6 +859,7 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
 __device__ __forceinline__ uint32_t h_key(uint32_t b) { return (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u); }
 __device__ __forceinline__ uint32_t h_unkey(uint32_t k) { return (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu); }
 
+#if MQ_PART == 0
 __global__ __launch_bounds__(256) void k_tensor_reduce(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   uint32_t* tred = const_cast<uint32_t*>(p.tred);
@@ -887,6 +896,8 @@ __global__ __launch_bounds__(256) void k_tensor_reduce(const QuantBatch b) {
     atomicMax(&tred[2], nkmin);
   }
 }
+
+#endif  // MQ_PART == 0
 
 template <int FMT, int NV>
 __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
@@ -1044,6 +1055,7 @@ __global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
 
 // Sum of a tensor's per-workgroup partials in a fixed order -> totals[0..1] (and seg_sse[0] for
 // per-tensor quantization).  One workgroup per tensor of the batch.
+#if MQ_PART == 0
 __global__ __launch_bounds__(256) void k_finalize_totals(const QuantBatch b, int nblocks, int tensor_scope) {
   __shared__ double lds[32];
   const BatchItem& it = b.item[blockIdx.x];
@@ -1063,9 +1075,12 @@ __global__ __launch_bounds__(256) void k_finalize_totals(const QuantBatch b, int
   }
 }
 
+#endif  // MQ_PART == 0
+
 // ================================================================================================
 // host side
 // ================================================================================================
+#if MQ_PART == 0
 static int ilog2_ceil(int64_t x) {
   int l = 0;
   while (((int64_t)1 << l) < x) ++l;
@@ -1129,6 +1144,9 @@ static bool recip_ok_cached(float c) {
   return ok;
 }
 
+#endif  // MQ_PART == 0
+
+#if MQ_PART >= 1
 template <int FMT, int NV, int SEL>
 static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
   switch (team_log2) {
@@ -1169,6 +1187,26 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
   }
 }
 
+
+#endif  // MQ_PART >= 1
+
+// One format's kernels per translation unit.
+#if MQ_PART >= 1
+#define MQ_PART_FMT (MQ_PART - 1)  // MQ_INT_SYM, MQ_INT_ASYM, MQ_LUT_FP
+#define MQ_CAT2(a, b) a##b
+#define MQ_CAT(a, b) MQ_CAT2(a, b)
+void MQ_CAT(mq_launch_fmt, MQ_PART)(int sel_mode, int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds,
+                                    hipStream_t st, const QuantBatch& b) {
+  if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_PART_FMT, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
+  else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_PART_FMT, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
+  else launch_fmt<MQ_PART_FMT, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
+}
+#endif
+
+#if MQ_PART == 0
+void mq_launch_fmt1(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+void mq_launch_fmt2(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+void mq_launch_fmt3(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
 #include <vector>
@@ -1354,21 +1392,9 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     MQ_HIP(hipEventRecord(e0, st));
   }
   switch (fmt) {
-    case MQ_INT_SYM:
-      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_INT_SYM, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_INT_SYM, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_INT_SYM, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
-      break;
-    case MQ_INT_ASYM:
-      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_INT_ASYM, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_INT_ASYM, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_INT_ASYM, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
-      break;
-    default:
-      if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_LUT_FP, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_LUT_FP, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
-      else launch_fmt<MQ_LUT_FP, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
-      break;
+    case MQ_INT_SYM: mq_launch_fmt1(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    case MQ_INT_ASYM: mq_launch_fmt2(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    default: mq_launch_fmt3(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
   }
   MQ_HIP(hipGetLastError());
   if (timed) MQ_HIP(hipEventRecord(prof_events.back(), st));
@@ -1475,3 +1501,4 @@ extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, 
   }
   return MQ_OK;
 }
+#endif  // MQ_PART == 0
