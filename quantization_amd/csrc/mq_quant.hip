@@ -1160,33 +1160,37 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
   }
 }
 
-// SEL: the variants that feed a percentile selection (team / wave / workgroup scopes only).
+// SEL: SEL_FEED_OFF, or the two passes that feed a percentile selection (team scope only: rows are not fed).
 template <int FMT, int SEL>
 static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
                        const QuantBatch& p) {
   if (scope == SC_SUBWAVE) {
     launch_team<FMT, 4, SEL>(team_log2, grid, lds, st, p);
-  } else if (scope == SC_WAVE) {
-    switch (nv) {
-      case 2: hipLaunchKernelGGL((k_quant_wave<FMT, 2, SEL>), grid, dim3(256), lds, st, p); break;
-      case 4: hipLaunchKernelGGL((k_quant_wave<FMT, 4, SEL>), grid, dim3(256), lds, st, p); break;
-      case 8: hipLaunchKernelGGL((k_quant_wave<FMT, 8, SEL>), grid, dim3(256), lds, st, p); break;
-      default: hipLaunchKernelGGL((k_quant_wave<FMT, 16, SEL>), grid, dim3(256), lds, st, p); break;
-    }
-  } else if (scope == SC_BLOCK) {
-    if (threads == 256) {
-      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 256, SEL>), grid, dim3(256), lds, st, p);
-      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 256, SEL>), grid, dim3(256), lds, st, p);
+    return;
+  }
+  if constexpr (SEL == SEL_FEED_OFF) {
+    if (scope == SC_WAVE) {
+      switch (nv) {
+        case 2: hipLaunchKernelGGL((k_quant_wave<FMT, 2, SEL>), grid, dim3(256), lds, st, p); break;
+        case 4: hipLaunchKernelGGL((k_quant_wave<FMT, 4, SEL>), grid, dim3(256), lds, st, p); break;
+        case 8: hipLaunchKernelGGL((k_quant_wave<FMT, 8, SEL>), grid, dim3(256), lds, st, p); break;
+        default: hipLaunchKernelGGL((k_quant_wave<FMT, 16, SEL>), grid, dim3(256), lds, st, p); break;
+      }
+    } else if (scope == SC_BLOCK) {
+      if (threads == 256) {
+        if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 256, SEL>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((k_quant_block<FMT, 16, 256, SEL>), grid, dim3(256), lds, st, p);
+      } else {
+        if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 1024, SEL>), grid, dim3(1024), lds, st, p);
+        else hipLaunchKernelGGL((k_quant_block<FMT, 16, 1024, SEL>), grid, dim3(1024), lds, st, p);
+      }
+    } else if (scope == SC_TENSOR) {
+      hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
     } else {
-      if (nv == 8) hipLaunchKernelGGL((k_quant_block<FMT, 8, 1024, SEL>), grid, dim3(1024), lds, st, p);
-      else hipLaunchKernelGGL((k_quant_block<FMT, 16, 1024, SEL>), grid, dim3(1024), lds, st, p);
+      hipLaunchKernelGGL((k_quant_generic<FMT>), grid, dim3(256), 0, st, p);
     }
-  } else if constexpr (SEL == SEL_FEED_OFF) {
-    if (scope == SC_TENSOR) hipLaunchKernelGGL((k_quant_tensor<FMT, 4>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_quant_generic<FMT>), grid, dim3(256), 0, st, p);
   }
 }
-
 
 #endif  // MQ_PART >= 1
 
