@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 import quantization_amd as qa  # noqa: E402
 from quantization_amd import _lib  # noqa: E402
-from quantization_amd.error_metrics import percentile_multi, vector_mse_stats  # noqa: E402
+from quantization_amd.error_metrics import percentile_multi, true_div  # noqa: E402
 from quantization_amd.fused import QuantResult, quantize_batch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
@@ -142,10 +142,11 @@ class Workload:
             vecs = [res.seg_sse[i] for res in results for i in range(res.seg_sse.shape[0])]
             rec[:, 3] = percentile_multi(vecs, 99) / self.vec_len
         else:
-            row = 0
+            vecs = []
             for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
-                rec[row:row + w.shape[0], 3] = vector_mse_stats(res.seg_sse, gs if gs else w.shape[2], 99)[1]
-                row += w.shape[0]
+                per_vec = true_div(res.seg_sse, gs if gs else w.shape[2])   # IEEE division, as the scripts divide
+                vecs += [per_vec[i] for i in range(per_vec.shape[0])]
+            rec[:, 3] = percentile_multi(vecs, 99)
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
         return [rec]

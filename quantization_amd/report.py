@@ -8,7 +8,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .error_metrics import error_stats, percentile, true_div, vector_mse_stats
+from .error_metrics import error_stats, percentile, percentile_multi, true_div
 from .fused import LUT_FORMATS, quantize, quantize_batch
 
 MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
@@ -101,6 +101,7 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         if w.dim() != 2:
             raise ValueError("model_records() takes 2-D weights")
         groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
+    vec_rows, vecs = [], []  # per-vector MSE lists of ALL layers: one set of select launches at the end
     for (shape, _), idx in groups.items():
         K, C = shape
         L = C if granularity(group_size) == "per-channel" else group_size
@@ -118,10 +119,15 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
             rec = torch.zeros(len(sel), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
             rec[:, 0] = K * C
             rec[:, 1:3] = res.totals
-            rec[:, 3], rec[:, 4] = vector_mse_stats(res.seg_sse.contiguous(), L, pct)
+            per_vec = true_div(res.seg_sse, L)        # a fresh tensor: the chunk's buffers are reused
+            rec[:, 3] = per_vec.mean(dim=1)
             if abs_p99:
                 rec[:, 5] = res.abs_p99.double()
             out[rows] = rec
+            vec_rows += sel
+            vecs += [per_vec[i] for i in range(len(sel))]
+    for lo in range(0, len(vecs), 4096):
+        out[torch.as_tensor(vec_rows[lo:lo + 4096], device=dev), 4] = percentile_multi(vecs[lo:lo + 4096], pct)
     return out
 
 
