@@ -130,6 +130,43 @@ int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, int32_t w_d
                           const mq_quant_cfg* cfg, double pct, float* p99, void* workspace, size_t workspace_bytes,
                           void* hip_stream);
 
+/*
+ * Value tables given as explicit lists: the reference's formats whose values have no (E, M, bias) closed form
+ * (FP3 quant_weight.py:11, FLINT4 :20, FLINT5 :36, the FP3/FP4 *_er_* / *_ea_* lists :12-15, :24-31), FP8_E5M2
+ * :139-169, whose path runs in float32 (:505-540, :796-826), and the MX path (quant_mx :337-380).
+ * The chosen entry is the one with mid[i-1] < x <= mid[i], mid[i] = (values[i] + values[i+1]) / 2 (a NaN x
+ * gives 0, :590-595); per-segment results are as for mq_quantize.
+ */
+typedef enum {
+  MQ_TABLE_F16 = 0, /* float16 op by op, as MQ_LUT_FP: quant_datatype :577-601, _fp_quant_meta :829-872;
+                       deq / codes / scale are float16 */
+  MQ_TABLE_F32 = 1, /* float32: scale = clamp(max|w32| / qmax, 1e-5, 1e4), x = w32 / scale, deq = q * scale.
+                       quant_datatype's per-tensor branch :562-575 (deq_dtype MQ_F16: the product is rounded to
+                       float16) and the FP8_E5M2 path :505-540, :796-826 (deq_dtype MQ_F32); codes and scale
+                       are float32 */
+  MQ_TABLE_MX = 2   /* quant_mx :337-380: per group e = floor(log2(max|w32|)), x = (w32 / 2^e) / (2 / qmax),
+                       deq = float16((q * (2 / qmax)) * 2^e); group_size must be > 0; only deq and the error
+                       outputs are produced (codes, scale and zero_point must be NULL) */
+} mq_table_math;
+
+#define MQ_TABLE_MAX_VALUES 256
+#define MQ_TABLE_NEG_INF_ZERO 1 /* flags: x = -inf selects 0, not values[0]: the (edge[i] < x) test of the
+                                   FP8_E5M2 loop (quant_weight.py:535-538) has no entry for it */
+typedef struct {
+  int32_t math;       /* mq_table_math */
+  int32_t count;      /* number of values, 2 .. MQ_TABLE_MAX_VALUES, strictly ascending */
+  int32_t deq_dtype;  /* MQ_F16, or MQ_F32 (MQ_TABLE_F32 only) */
+  int32_t flags;      /* MQ_TABLE_NEG_INF_ZERO or 0 */
+  int64_t group_size; /* as mq_quant_cfg */
+  float values[MQ_TABLE_MAX_VALUES];
+} mq_table_cfg;
+
+size_t mq_quantize_table_workspace_bytes(int64_t rows, int64_t cols, const mq_table_cfg* cfg);
+/* out->abs_err / seg_sse / totals: errors float32(float16(w)) - float32(deq), as for mq_quantize.  These formats
+ * are off the bandwidth-critical path: one wave (or workgroup) per segment, scalar element accesses. */
+int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_table_cfg* cfg,
+                      const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Bytes of device workspace mq_percentile needs (histograms + selection state). */
 size_t mq_percentile_workspace_bytes(void);
 

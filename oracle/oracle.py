@@ -51,6 +51,15 @@ class _Cfg(ctypes.Structure):
                 ("group_size", ctypes.c_int64)]
 
 
+TABLE_F16, TABLE_F32, TABLE_MX = 0, 1, 2
+TABLE_NEG_INF_ZERO = 1
+
+
+class _TableCfg(ctypes.Structure):
+    _fields_ = [("math", ctypes.c_int32), ("count", ctypes.c_int32), ("deq_f32", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("group_size", ctypes.c_int64), ("values", ctypes.c_float * 256)]
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libmq_oracle.so")
     src = os.path.join(_HERE, "mq_oracle.c")
@@ -87,6 +96,8 @@ def lib():
         L.orc_build_lut_sub.restype = ctypes.c_int
         L.orc_lut_round_f16_sub.argtypes = L.orc_lut_round_f16.argtypes
         L.orc_lut_round_f16_sub.restype = ctypes.c_uint16
+        L.orc_quantize_table.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.POINTER(_TableCfg), vp, vp, vp]
+        L.orc_quantize_table.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -137,6 +148,37 @@ def quantize(w, dtype, fmt, bits=8, group_size=None, datatype=None, lut_f32_path
     rc = lib().orc_quantize_rows_mt(w.ctypes.data, dtype, K, C, ctypes.byref(cfg), _ptr(out.get("v16")),
                                     _ptr(out.get("deq")), _ptr(out.get("q")), _ptr(out.get("scale")),
                                     _ptr(out.get("zp")), int(nthreads))
+    if rc == -2:
+        raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {n}")
+    if rc:
+        raise ValueError(f"oracle: bad argument (rc={rc})")
+    return out
+
+
+def quantize_table(w, dtype, values, math, group_size=None, deq_f32=False, neg_inf_zero=False):
+    """Explicit value lists (quant_weight.py:503-601 for the irregular tables, :505-540 FP8_E5M2, :337-380 MX).
+
+    Returns {"deq": uint16 float16 bits or float32 [K,C], "q": float16 bits / float32 [K,C] (absent for MX),
+    "scale": float16 bits / float32 [nseg] (absent for MX)}."""
+    assert w.ndim == 2 and w.flags.c_contiguous
+    K, C = w.shape
+    gs = 0 if group_size is None else int(group_size)
+    if gs < -1:
+        gs = 0
+    cfg = _TableCfg(math=math, count=len(values), deq_f32=int(bool(deq_f32)), group_size=gs,
+                    flags=TABLE_NEG_INF_ZERO if neg_inf_zero else 0)
+    for i, v in enumerate(values):
+        cfg.values[i] = v
+    n = K * C
+    L = n if gs == -1 else (C if gs <= 0 else gs)
+    nseg = n // L if L else 0
+    wide = np.uint16 if math == TABLE_F16 else np.float32
+    out = {"deq": np.empty((K, C), np.float32 if deq_f32 else np.uint16)}
+    if math != TABLE_MX:
+        out["q"] = np.empty((K, C), wide)
+        out["scale"] = np.empty(nseg, wide)
+    rc = lib().orc_quantize_table(w.ctypes.data, dtype, K, C, ctypes.byref(cfg), _ptr(out["deq"]),
+                                  _ptr(out.get("q")), _ptr(out.get("scale")))
     if rc == -2:
         raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {n}")
     if rc:

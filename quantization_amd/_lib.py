@@ -11,6 +11,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmq.so")
 
 F16, BF16, F32 = 0, 1, 2
 INT_SYM, INT_ASYM, LUT_FP, LUT_FP_SUB = 0, 1, 2, 3
+TABLE_F16, TABLE_F32, TABLE_MX = 0, 1, 2
+TABLE_MAX_VALUES = 256
+TABLE_NEG_INF_ZERO = 1
 
 OK, ERR_ARG, ERR_GROUP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_ALIGN = 0, -1, -2, -3, -4, -5, -6
 
@@ -25,6 +28,12 @@ class QuantOut(ctypes.Structure):
     _fields_ = [("deq", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("scale", ctypes.c_void_p),
                 ("zero_point", ctypes.c_void_p), ("abs_err", ctypes.c_void_p), ("abs_err_dtype", ctypes.c_int32),
                 ("reserved", ctypes.c_int32), ("seg_sse", ctypes.c_void_p), ("totals", ctypes.c_void_p)]
+
+
+class TableCfg(ctypes.Structure):
+    _fields_ = [("math", ctypes.c_int32), ("count", ctypes.c_int32), ("deq_dtype", ctypes.c_int32),
+                ("flags", ctypes.c_int32), ("group_size", ctypes.c_int64),
+                ("values", ctypes.c_float * TABLE_MAX_VALUES)]
 
 
 class MqError(RuntimeError):
@@ -56,6 +65,10 @@ def lib():
         L.mq_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]
         L.mq_quantize.restype = ctypes.c_int
         L.mq_quantize.argtypes = [vp, i32, i64, i64, ctypes.POINTER(QuantCfg), ctypes.POINTER(QuantOut), vp, sz, vp]
+        L.mq_quantize_table_workspace_bytes.restype = sz
+        L.mq_quantize_table_workspace_bytes.argtypes = [i64, i64, ctypes.POINTER(TableCfg)]
+        L.mq_quantize_table.restype = ctypes.c_int
+        L.mq_quantize_table.argtypes = [vp, i32, i64, i64, ctypes.POINTER(TableCfg), ctypes.POINTER(QuantOut), vp, sz, vp]
         _lib = L
     return _lib
 

@@ -24,6 +24,37 @@ LUT_FORMATS = {"fp8_e4m3": (4, 3, 7), "fp8_e3m4": (3, 4, 3), "fp8_e2m5": (2, 5, 
 LUT_SUBNORMAL = {"fp4", "fp5", "fp5_e2m2", "fp5_e3m1", "fp6", "fp6_e2m3", "fp6_e3m2",
                  "int3", "int4", "int5", "int6", "int8"}
 
+
+
+def _mirrored(positive):
+    return [-v for v in reversed(positive)] + [0.0] + [float(v) for v in positive]
+
+
+def _with(values, extra):
+    return sorted(values + [float(extra)])
+
+
+_FP3 = _mirrored([1, 2, 4])
+_FP4 = _mirrored([1, 2, 3, 4, 6, 8, 12])
+# Value lists without a closed form (reference: quant_weight.py FP3 :11, FP3_ER_* / FP3_EA_* :12-15 = FP3 plus
+# one value, FLINT4 :20, FP4_ER_* / FP4_EA_* :24-31 = FP4_E2M1 plus one value, FLINT5 :36), quantized by
+# mq_quantize_table.  tests/golden/lut_tables.json pins them to the reference's lists.
+TABLE_LISTS = {
+    "fp3": _FP3,
+    "fp3_er_pos": _with(_FP3, 3), "fp3_er_neg": _with(_FP3, -3),
+    "fp3_ea_pos": _with(_FP3, 6), "fp3_ea_neg": _with(_FP3, -6),
+    "flint4": _mirrored([1, 2, 3, 4, 6, 8, 16]),
+    "fp4_er_pos": _with(_FP4, 10), "fp4_er_neg": _with(_FP4, -10),
+    "fp4_ea_pos": _with(_FP4, 16), "fp4_ea_neg": _with(_FP4, -16),
+    "flint5": _mirrored([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 24, 32, 64]),
+    # FP8_E5M2 :139-169: +-(1 + m/4) * 2^(e-15) over all 32 exponent codes, (e=0, m=0) being the zero; its
+    # path runs in float32 (:505-540)
+    "fp8_e5m2": _mirrored([(1 + m / 4) * 2.0 ** (e - 15) for e in range(32) for m in range(4) if e or m]),
+}
+# quant_mx's tables (quant_weight.py:177-188)
+MX_TABLES = {"mx_int3": _mirrored([1, 2, 3]), "mx_fp3": _FP3,
+             "mx_int4": _mirrored([1, 2, 3, 4, 5, 6, 7]), "mx_fp4": _FP4}
+
 _DTYPES = {torch.float16: _lib.F16, torch.bfloat16: _lib.BF16, torch.float32: _lib.F32}
 _workspaces = {}
 
@@ -252,5 +283,65 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
             ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
             st = L_.mq_quantize_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
                                       ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return res
+
+
+@torch.no_grad()
+def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_dtype=torch.float16,
+                   neg_inf_zero=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False,
+                   totals=False) -> QuantResult:
+    """quantize() for a value table given as an explicit ascending list (mq_quantize_table): math is
+    _lib.TABLE_F16 (float16 op by op; codes / scale float16), _lib.TABLE_F32 (float32; codes / scale float32,
+    deq float16 or float32) or _lib.TABLE_MX (shared power-of-two exponent per group; deq only)."""
+    if w.dtype not in _DTYPES:
+        raise ValueError(f"unsupported weight dtype {w.dtype}")
+    if not w.is_cuda:
+        raise RuntimeError("quantize_table() expects a ROCm device tensor")
+    if not 2 <= len(values) <= _lib.TABLE_MAX_VALUES:
+        raise ValueError("a value table holds 2 .. 256 entries")
+    cols = w.shape[-1] if w.dim() else 1
+    rows = w.numel() // cols if cols else 0
+    w2 = w.contiguous()
+    gs = 0 if group_size is None else int(group_size)
+    if gs < -1:
+        gs = 0
+    n = rows * cols
+    L = n if gs == -1 else (cols if gs <= 0 else gs)
+    if gs > 0 and cols % gs:
+        raise RuntimeError(f"shape '[{rows}, {cols // gs}, {gs}]' is invalid for input of size {n}")
+    nseg = n // L if L else 0
+    cfg = _lib.TableCfg(math=math, count=len(values), group_size=gs,
+                        deq_dtype=_lib.F32 if deq_dtype == torch.float32 else _lib.F16,
+                        flags=_lib.TABLE_NEG_INF_ZERO if neg_inf_zero else 0)
+    for i, v in enumerate(values):
+        cfg.values[i] = v
+    dev = w.device
+    wide = torch.float16 if math == _lib.TABLE_F16 else torch.float32
+    if math == _lib.TABLE_MX:
+        codes = scale = False
+    res = QuantResult(rows, cols, nseg)
+
+    def buf(want, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=dev) if want else None
+
+    res.deq = buf(deq, (rows, cols), deq_dtype)
+    res.codes = buf(codes, (rows, cols), wide)
+    res.scale = buf(scale, (nseg,), wide)
+    res.abs_err = buf(abs_err is not None, (rows, cols), abs_err or torch.float32)
+    res.seg_sse = buf(seg_sse, (nseg,), torch.float64)
+    res.totals = buf(totals, (2,), torch.float64)
+    if n == 0:
+        if res.totals is not None:
+            res.totals.zero_()
+        return res
+    L_ = _lib.lib()
+    o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale), zero_point=None,
+                      abs_err=_ptr(res.abs_err), abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
+                      seg_sse=_ptr(res.seg_sse), totals=_ptr(res.totals))
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L_.mq_quantize_table_workspace_bytes(rows, cols, ctypes.byref(cfg)))
+        st = L_.mq_quantize_table(w2.data_ptr(), _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ctypes.byref(o),
+                                  ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return res

@@ -5,13 +5,14 @@ Same function names, argument meaning, return shapes/dtypes and exception types 
 kernel behind include/mq.h.  A host tensor is moved to the current ROCm device and the result moved
 back, so the reference's CPU-tensor call sites keep working; there is no CPU compute path.
 
-Supported on the device: symmetric / asymmetric INT with 2..8 bits, and every value-table format of the
-reference that is a regular minifloat grid -- fp8_e4m3, fp8_e3m4, fp8_e2m5 (no subnormals: packed fast
-path), fp4, fp5 / fp5_e2m2, fp5_e3m1, fp6 / fp6_e2m3, fp6_e3m2 and the INTn lists when passed to
-quant_datatype (tables with subnormals: per-element path) -- each per-tensor (group_size == -1),
-per-channel (None / 0 / other negatives) or per-group (> 0).  The irregular tables (fp3*, flint*, the
-*_er_* / *_ea_* variants), fp8_e5m2's float32 path, MX and the mixed-datatype search are not implemented
-and raise NotImplementedError.
+Supported on the device: symmetric / asymmetric INT with 2..8 bits and every value-table format of the
+reference, each per-tensor (group_size == -1), per-channel (None / 0 / other negatives) or per-group (> 0):
+  * regular minifloat grids through the fused kernels -- fp8_e4m3, fp8_e3m4, fp8_e2m5 (no subnormals: packed
+    fast path), fp4, fp5 / fp5_e2m2, fp5_e3m1, fp6 / fp6_e2m3, fp6_e3m2 and the INTn lists when passed to
+    quant_datatype (tables with subnormals: per-element path);
+  * the irregular lists (fp3, flint4, flint5, the *_er_* / *_ea_* variants), fp8_e5m2's float32 path and MX
+    (quant_mx) through the explicit-table kernel (mq_quantize_table).
+The mixed-datatype search (search_datatype) is not implemented and raises NotImplementedError.
 """
 from typing import Optional
 
@@ -20,7 +21,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .fused import LUT_FORMATS, quantize, quantize_batch, require_device
+from .fused import (LUT_FORMATS, MX_TABLES, TABLE_LISTS, quantize, quantize_batch, quantize_table,
+                    require_device)
 
 # names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
 # ValueError / AssertionError behaviour for unknown names
@@ -56,9 +58,22 @@ def _check_table(wq_bits, datatype):
         # quant_weight.py:552-554 / :790-791
         raise ValueError(f"Currently only support 3-, 4-, 5-,6- and 8-bit quantization, not {wq_bits}-bit")
     assert datatype in _KNOWN_TABLES[wq_bits], f"unexpected data type {datatype}."  # :556 / :793
-    if datatype not in LUT_FORMATS:
-        raise NotImplementedError(f"value-table format {datatype!r} has no MI355X kernel yet "
-                                  f"(supported: {sorted(LUT_FORMATS)})")
+
+
+def _table_run(w, datatype, group_size, math, **kw):
+    """The explicit-list formats (TABLE_LISTS); same conventions as _run."""
+    if _is_per_group(group_size):
+        K, C = w.size()
+    dev = w.device
+    res = quantize_table(require_device(w), TABLE_LISTS[datatype], math, group_size, **kw)
+    return res, dev
+
+
+def _e5m2(w, group_size, meta):
+    """FP8_E5M2: float32 arithmetic and float32 results (quant_weight.py:505-540, :796-826)."""
+    res, dev = _table_run(w, "fp8_e5m2", group_size, _lib.TABLE_F32, deq_dtype=torch.float32, neg_inf_zero=True,
+                          codes=meta, scale=meta)
+    return res, dev
 
 
 @torch.no_grad()
@@ -79,10 +94,31 @@ def quant_int_asym(w_fp16, wq_bits: int = 4, group_size: Optional[int] = None):
 def quant_datatype(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Optional[int] = None):
     """Nearest-value quantization to a format's value table (quant_weight.py:503-601).  The per-tensor
     branch computes in float32 as the reference does (:562-575)."""
+    if datatype == "fp8_e5m2":  # tested before the bit width, as in the reference (:505)
+        res, dev = _e5m2(w_fp16, group_size, meta=False)
+        return res.deq.reshape(w_fp16.shape).to(dev)
     _check_table(wq_bits, datatype)
-    res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype, f32_math=_is_per_tensor(group_size),
-                    codes=False, scale=False)
+    if datatype in TABLE_LISTS:
+        math = _lib.TABLE_F32 if _is_per_tensor(group_size) else _lib.TABLE_F16
+        res, dev = _table_run(w_fp16, datatype, group_size, math, codes=False, scale=False)
+    else:
+        res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype, f32_math=_is_per_tensor(group_size),
+                        codes=False, scale=False)
     return res.deq.reshape(w_fp16.shape).to(dev)
+
+
+@torch.no_grad()
+def quant_mx(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: int = 32):
+    """MX quantization: a shared power-of-two exponent per group of group_size input channels
+    (quant_weight.py:337-380).  Returns the dequantized float16 weight."""
+    if wq_bits not in (3, 4):
+        raise ValueError(f"Currently only support 3-bit, 4-bit quantization, not {wq_bits}-bit")  # :348
+    names = {3: ("mx_int3", "mx_fp3"), 4: ("mx_int4", "mx_fp4")}[wq_bits]
+    assert datatype in names, f"unexpected data type {datatype}."  # :351
+    K, C = w_fp16.size()
+    dev = w_fp16.device
+    res = quantize_table(require_device(w_fp16), MX_TABLES[datatype], _lib.TABLE_MX, group_size)
+    return res.deq.reshape(K, C).to(dev)
 
 
 @torch.no_grad()
@@ -117,9 +153,17 @@ def _shape_int_meta(shape, asym, group_size, codes, scale, zero_point):
 
 @torch.no_grad()
 def _fp_quant_meta(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Optional[int] = None):
-    """(w_deq float16, q float16 table values, scale float16) -- quant_weight.py:778-872."""
+    """(w_deq float16, q float16 table values, scale float16) -- quant_weight.py:778-872; all three are
+    float32 for fp8_e5m2 (:796-826), whose q keeps the weight's shape also per group (:824)."""
     _check_table(wq_bits, datatype)
-    res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype)
+    if datatype == "fp8_e5m2":
+        res, dev = _e5m2(w_fp16, group_size, meta=True)
+        _, scale = _shape_fp_meta(w_fp16.shape, group_size, res.codes, res.scale)
+        return (res.deq.reshape(w_fp16.shape).to(dev), res.codes.reshape(w_fp16.shape).to(dev), scale.to(dev))
+    if datatype in TABLE_LISTS:
+        res, dev = _table_run(w_fp16, datatype, group_size, _lib.TABLE_F16)
+    else:
+        res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype)
     w_deq = res.deq.reshape(w_fp16.shape)
     q, scale = _shape_fp_meta(w_fp16.shape, group_size, res.codes, res.scale)
     return w_deq.to(dev), q.to(dev), scale.to(dev)
@@ -155,8 +199,12 @@ class _LinearDump(nn.Linear):
         else:
             _, q, scale = _fp_quant_meta(self.weight.data, wq_bits=wq_bits, datatype=mode, group_size=group_size)
             zp = None
-        self.register_buffer("weight_q", q.to(torch.float16))
-        self.register_buffer("weight_scale", scale.to(torch.float16))
+        if mode == "fp8_e5m2":  # float32 buffers (:898-900)
+            self.register_buffer("weight_q", q)
+            self.register_buffer("weight_scale", scale)
+        else:
+            self.register_buffer("weight_q", q.to(torch.float16))
+            self.register_buffer("weight_scale", scale.to(torch.float16))
         if zp is not None:
             self.register_buffer("weight_zp", zp)
 
@@ -189,12 +237,28 @@ def quant_model(model, wq_bits: Optional[int] = None, wq_datatype: Optional[str]
         fmt, table = (_lib.INT_ASYM if asym else _lib.INT_SYM), None
         kind = "asymmetric" if asym else "symmetric"
         print(f"Applying {kind} INT quantization with bits: {wq_bits}, group size: {wq_groupsize}")
-    elif "mx" in wq_datatype or "mixed" in wq_datatype:
-        raise NotImplementedError(f"{wq_datatype}: MX / mixed-datatype search have no MI355X kernel yet")
+    elif "mx" in wq_datatype:
+        # hard-coded group size 32, and no _LinearDump for these names (:674-686, :929-930)
+        print(f"Applying MX quantization with bits: {wq_bits}, datatype: {wq_datatype}, group size: 32")
+        for _, m in _linears(model):
+            m.weight.data = quant_mx(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype, group_size=32)
+        return
+    elif "mixed" in wq_datatype:
+        raise NotImplementedError(f"{wq_datatype}: the mixed-datatype search has no MI355X kernel yet")
     elif "fp" in wq_datatype:
+        print(f"Applying floating-point datatype quantization with bits: {wq_bits}, group size: {wq_groupsize}")
+        if wq_datatype in TABLE_LISTS:
+            # explicit-list formats: layer by layer through the table kernel, then the reference's _LinearDump
+            for _, m in _linears(model):
+                m.weight.data = quant_datatype(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype,
+                                               group_size=wq_groupsize)
+            if _dump_int:
+                for name, mod in _linears(model):
+                    parent, attr = _find_parent(model, name)
+                    setattr(parent, attr, _LinearDump(mod, wq_bits, wq_datatype, wq_groupsize))
+            return
         _check_table(wq_bits, wq_datatype)
         asym, fmt, table = False, _lib.LUT_FP, wq_datatype
-        print(f"Applying floating-point datatype quantization with bits: {wq_bits}, group size: {wq_groupsize}")
     else:
         raise ValueError(f"Unsupported datatype {wq_datatype}")
 

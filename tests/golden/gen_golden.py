@@ -15,6 +15,9 @@ Files written:
   quant_more_formats.npz  the formats beyond the 8-bit headline set: value tables fp4, fp5_e2m2, fp5_e3m1,
                         fp6_e2m3, fp6_e3m2, fp8_e2m5 and the INTn lists used as tables (int3, int4, int6),
                         4-bit INT sym / asym; small inputs, all float16 patterns, the rounding-domain sweep
+  quant_table_formats.npz  the explicit-list formats: fp3, flint4, flint5 and the *_er_* / *_ea_* lists
+                        (_fp_quant_meta + quant_datatype), fp8_e5m2 (float32 results) and quant_mx; small inputs,
+                        non-finite inputs, and all float16 patterns for a subset
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
@@ -157,10 +160,80 @@ _MAPPING = {3: qw.DATATYPE_MAPPING_3_BIT, 4: qw.DATATYPE_MAPPING_4_BIT, 5: qw.DA
             6: qw.DATATYPE_MAPPING_6_BIT, 8: qw.DATATYPE_MAPPING_8_BIT}
 
 
+LIST_TABLES = [(3, "fp3"), (3, "fp3_er_pos"), (3, "fp3_er_neg"), (3, "fp3_ea_pos"), (3, "fp3_ea_neg"),
+               (4, "flint4"), (4, "fp4_er_pos"), (4, "fp4_er_neg"), (4, "fp4_ea_pos"), (4, "fp4_ea_neg"),
+               (5, "flint5")]
+MX_TABLES = [(3, "mx_int3"), (3, "mx_fp3"), (4, "mx_int4"), (4, "mx_fp4")]
+_MX_MAPPING = {3: qw.DATATYPE_MAPPING_3_BIT_MX, 4: qw.DATATYPE_MAPPING_4_BIT_MX}
+
+
 def gen_lut_tables():
+    tables = {name: list(map(float, _MAPPING[bits][name])) for bits, name in ALL_TABLES + LIST_TABLES}
+    tables["fp8_e5m2"] = list(map(float, qw.DATATYPE_MAPPING_8_BIT["fp8_e5m2"]))
+    tables.update({name: list(map(float, _MX_MAPPING[bits][name])) for bits, name in MX_TABLES})
     with open(os.path.join(HERE, "lut_tables.json"), "w") as f:
-        json.dump({name: list(map(float, _MAPPING[bits][name])) for bits, name in ALL_TABLES}, f)
+        json.dump(tables, f)
     print("lut_tables.json")
+
+
+def gen_table_formats():
+    gen = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    K, C = 8, 512
+    arrays = {}
+    inputs = {}
+    for name, w in distributions(K, C, gen):
+        if name in ("normal", "heavy", "zerorows", "student_t", "tiny"):
+            inputs[f"{name}.f16"] = w.half()
+        if name == "normal":
+            inputs["normal.bf16"], inputs["normal.f32"] = w.bfloat16(), w.float()
+    sp = torch.randn(4, 512, generator=gen) * 0.02
+    sp[0, 3], sp[0, 7] = float("inf"), float("-inf")
+    sp[1, 5] = float("-inf")
+    sp[2, 9] = float("nan")
+    inputs["specials.f16"] = sp.half()
+    bits = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    allf16 = torch.from_numpy(bits.view(np.int16).copy()).view(torch.float16)
+    inputs["exhaustive.f16"] = torch.where(torch.isfinite(allf16), allf16, torch.zeros_like(allf16))
+    for name, w in inputs.items():
+        arrays[f"in/{name}"] = w.numpy().copy() if name.endswith(".f32") else bits16(w)
+
+    def groups(name, fmt):
+        if name.startswith("exhaustive"):
+            return [None] if fmt in ("flint4", "fp3_ea_neg", "flint5", "fp8_e5m2") else []
+        return [None, 64, -1]
+
+    for wq_bits, fmt in LIST_TABLES:
+        for name, w in inputs.items():
+            for gs in groups(name, fmt):
+                d, q, s = qw._fp_quant_meta(w, wq_bits=wq_bits, datatype=fmt, group_size=gs)
+                d2 = qw.quant_datatype(w, wq_bits=wq_bits, datatype=fmt, group_size=gs)
+                pre = f"out/{name}/{fmt}/{gs_key(gs)}/"
+                arrays[pre + "deq"], arrays[pre + "q"] = bits16(d), bits16(q)
+                arrays[pre + "scale"] = bits16(s.reshape(-1))
+                if gs == -1:  # the only scope where quant_datatype differs (float32 branch)
+                    arrays[pre + "deq_quant_datatype"] = bits16(d2.reshape_as(d))
+                else:
+                    assert torch.equal(bits_t(d2.reshape_as(d)), bits_t(d))
+    for name, w in inputs.items():
+        for gs in groups(name, "fp8_e5m2"):
+            d, q, s = qw._fp_quant_meta(w, wq_bits=8, datatype="fp8_e5m2", group_size=gs)
+            d2 = qw.quant_datatype(w, wq_bits=8, datatype="fp8_e5m2", group_size=gs)
+            assert d.dtype == q.dtype == s.dtype == torch.float32
+            assert np.array_equal(d2.reshape_as(d).numpy().view(np.uint32), d.numpy().view(np.uint32))
+            pre = f"out/{name}/fp8_e5m2/{gs_key(gs)}/"
+            arrays[pre + "deq"], arrays[pre + "q"] = d.numpy().copy(), q.numpy().copy()
+            arrays[pre + "scale"] = s.reshape(-1).numpy().copy()
+    for wq_bits, fmt in MX_TABLES:
+        for name, w in inputs.items():
+            if name.startswith("exhaustive") and fmt not in ("mx_fp4", "mx_int3"):
+                continue
+            for gs in ([32] if name.startswith("exhaustive") else [32, 128]):
+                d = qw.quant_mx(w, wq_bits=wq_bits, datatype=fmt, group_size=gs)
+                assert d.dtype == torch.float16
+                arrays[f"out/{name}/{fmt}/{gs}/deq"] = bits16(d)
+    np.savez_compressed(os.path.join(HERE, "quant_table_formats.npz"), **arrays)
+    print("quant_table_formats.npz", len(arrays), "arrays")
 
 
 def gen_more_formats():
@@ -283,8 +356,13 @@ if __name__ == "__main__":
         gen_lut_tables()
         gen_more_formats()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "tables":  # only the explicit-list formats
+        gen_lut_tables()
+        gen_table_formats()
+        sys.exit(0)
     gen_lut_tables()
     gen_more_formats()
+    gen_table_formats()
     gen_quant_small()
     gen_exhaustive()
     gen_lut_domain()

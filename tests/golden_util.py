@@ -63,3 +63,38 @@ def more_cases(fmt_key):
         exp = {kk[len(pre):]: z[kk] for kk in z if kk.startswith(pre)}
         out.append((name, z[f"in/{name}"], None if gk == "none" else int(gk), exp))
     return out
+
+
+# explicit-list formats (quant_table_formats.npz): (wq_bits, table name)
+LIST_TABLES = [(3, "fp3"), (3, "fp3_er_pos"), (3, "fp3_er_neg"), (3, "fp3_ea_pos"), (3, "fp3_ea_neg"),
+               (4, "flint4"), (4, "fp4_er_pos"), (4, "fp4_er_neg"), (4, "fp4_ea_pos"), (4, "fp4_ea_neg"),
+               (5, "flint5")]
+MX_TABLES = [(3, "mx_int3"), (3, "mx_fp3"), (4, "mx_int4"), (4, "mx_fp4")]
+
+
+def table_cases(fmt):
+    """-> list of (input name 'dist.dtype', array, group size, expected dict) of quant_table_formats.npz for one
+    format name (a LIST_TABLES / MX_TABLES name or 'fp8_e5m2')."""
+    z = npz("quant_table_formats.npz")
+    out = []
+    for k in sorted(z):
+        if not k.startswith("out/") or not k.endswith("/deq"):
+            continue
+        _, name, f, gk, _ = k.split("/")
+        if f != fmt:
+            continue
+        pre = f"out/{name}/{f}/{gk}/"
+        exp = {kk[len(pre):]: z[kk] for kk in z if kk.startswith(pre)}
+        out.append((name, z[f"in/{name}"], None if gk == "none" else int(gk), exp))
+    return out
+
+
+def same_values(got, want):
+    """Bitwise equality of two float16-bit (uint16) or float32 arrays, any NaN matching any NaN (the payload
+    and sign of a NaN produced by 0 * inf or inf / inf differ between CPUs and the GPU)."""
+    got, want = np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)
+    if got.dtype == np.uint16:
+        gn, wn = (got & 0x7FFF) > 0x7C00, (want & 0x7FFF) > 0x7C00
+        return bool(np.array_equal(gn, wn) and np.array_equal(got[~gn], want[~wn]))
+    gn, wn = np.isnan(got), np.isnan(want)
+    return bool(np.array_equal(gn, wn) and np.array_equal(got[~gn].view(np.uint32), want[~wn].view(np.uint32)))

@@ -65,7 +65,7 @@ def test_lut_domain_sweep(oracle, fmt):
 def test_lut_tables_closed_form(oracle):
     """Every table format the kernels support equals the reference's value list."""
     ref = gu.load_json("lut_tables.json")
-    assert set(ref) == set(oracle.LUT_FORMATS)
+    assert set(oracle.LUT_FORMATS) <= set(ref)
     for name, (e, m, b) in oracle.LUT_FORMATS.items():
         assert np.array_equal(oracle.build_lut(e, m, b, name in oracle.LUT_SUBNORMAL), np.array(ref[name])), name
 
@@ -87,6 +87,57 @@ def test_more_table_formats(oracle, bits, fmt):
     out = oracle.quantize(w, oracle.F16, oracle.LUT, bits, None, datatype=fmt)
     assert np.all(out["scale"] == 0x3C00)
     assert np.array_equal(out["q"], z[f"domain/{fmt}/q"].reshape(w.shape))
+
+
+def test_explicit_lists_match_reference():
+    """The value lists the product passes to mq_quantize_table equal the reference's lists."""
+    from quantization_amd import fused
+    ref = gu.load_json("lut_tables.json")
+    for name, values in list(fused.TABLE_LISTS.items()) + list(fused.MX_TABLES.items()):
+        assert [float(v) for v in values] == ref[name], name
+    assert set(ref) == set(fused.LUT_FORMATS) | set(fused.TABLE_LISTS) | set(fused.MX_TABLES)
+
+
+def _dtype_of(oracle, name):
+    return {"f16": oracle.F16, "bf16": oracle.BF16, "f32": oracle.F32}[name.rsplit(".", 1)[1]]
+
+
+@pytest.mark.parametrize("bits,fmt", gu.LIST_TABLES)
+def test_list_table_formats(oracle, bits, fmt):
+    """fp3 / flint4 / flint5 and the *_er_* / *_ea_* lists: _fp_quant_meta in float16 arithmetic for every scope,
+    quant_datatype's float32 branch per tensor."""
+    values = gu.load_json("lut_tables.json")[fmt]
+    cases = gu.table_cases(fmt)
+    assert cases
+    for name, w, gs, exp in cases:
+        out = oracle.quantize_table(w, _dtype_of(oracle, name), values, oracle.TABLE_F16, gs)
+        for k in ("deq", "q", "scale"):
+            assert gu.same_values(out[k], exp[k]), (name, gs, k)
+        if gs == -1:
+            out2 = oracle.quantize_table(w, _dtype_of(oracle, name), values, oracle.TABLE_F32, gs)
+            assert gu.same_values(out2["deq"], exp["deq_quant_datatype"]), (name, gs, "quant_datatype")
+
+
+def test_fp8_e5m2(oracle):
+    """FP8_E5M2: float32 arithmetic, float32 deq / q / scale (quant_weight.py:505-540, :796-826)."""
+    values = gu.load_json("lut_tables.json")["fp8_e5m2"]
+    cases = gu.table_cases("fp8_e5m2")
+    assert cases
+    for name, w, gs, exp in cases:
+        out = oracle.quantize_table(w, _dtype_of(oracle, name), values, oracle.TABLE_F32, gs, deq_f32=True,
+                                    neg_inf_zero=True)
+        for k in ("deq", "q", "scale"):
+            assert gu.same_values(out[k], exp[k]), (name, gs, k)
+
+
+@pytest.mark.parametrize("bits,fmt", gu.MX_TABLES)
+def test_quant_mx(oracle, bits, fmt):
+    values = gu.load_json("lut_tables.json")[fmt]
+    cases = gu.table_cases(fmt)
+    assert cases
+    for name, w, gs, exp in cases:
+        out = oracle.quantize_table(w, _dtype_of(oracle, name), values, oracle.TABLE_MX, gs)
+        assert gu.same_values(out["deq"], exp["deq"]), (name, gs)
 
 
 @pytest.mark.parametrize("fmt", ["int4", "int4_asym"])
