@@ -167,6 +167,20 @@ size_t mq_quantize_table_workspace_bytes(int64_t rows, int64_t cols, const mq_ta
 int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_table_cfg* cfg,
                       const mq_quant_out* out, void* workspace, size_t workspace_bytes, void* hip_stream);
 
+/*
+ * search_datatype (quant_weight.py:604-649): every segment (row, or group of group_size elements; -1 means rows
+ * here too, :631-632) of a float16 weight is quantized with each of ntables <= 8 value lists of at most 32
+ * entries (MQ_TABLE_F16 arithmetic; tables[i].group_size / math / deq_dtype are ignored) and keeps the first
+ * list whose error h(h(sum_f32 h(h(d - v)^2)) ... / L) -- the float16 (tmp - w).pow(2).mean(-1) -- is strictly
+ * below the best so far, starting from 1000; a segment no list improves stays 0.  deq: float16 [rows*cols];
+ * choice (optional): uint8 [nseg], the index of the chosen list or 255.  The float16 squares are multiples of
+ * 2^-24, so while a segment's sum stays below 1 every float32 summation order gives the same, exact sum: there
+ * the result equals torch's bit for bit; beyond it torch's own result depends on the host's vector width.
+ * No workspace is needed.
+ */
+int mq_search_tables(const void* w_f16, int64_t rows, int64_t cols, int64_t group_size, const mq_table_cfg* tables,
+                     int32_t ntables, void* deq, uint8_t* choice, void* hip_stream);
+
 /* Bytes of device workspace mq_percentile needs (histograms + selection state). */
 size_t mq_percentile_workspace_bytes(void);
 

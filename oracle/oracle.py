@@ -98,6 +98,8 @@ def lib():
         L.orc_lut_round_f16_sub.restype = ctypes.c_uint16
         L.orc_quantize_table.argtypes = [vp, ctypes.c_int, i64, i64, ctypes.POINTER(_TableCfg), vp, vp, vp]
         L.orc_quantize_table.restype = ctypes.c_int
+        L.orc_search_tables.argtypes = [vp, i64, i64, i64, ctypes.POINTER(_TableCfg), ctypes.c_int, vp, vp]
+        L.orc_search_tables.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -181,6 +183,28 @@ def quantize_table(w, dtype, values, math, group_size=None, deq_f32=False, neg_i
                                   _ptr(out.get("q")), _ptr(out.get("scale")))
     if rc == -2:
         raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {n}")
+    if rc:
+        raise ValueError(f"oracle: bad argument (rc={rc})")
+    return out
+
+
+def search_tables(w16_bits, tables, group_size=None):
+    """search_datatype (quant_weight.py:604-649) on float16 bits [K, C]: tables is a list of value lists.
+    -> {"deq": uint16 [K, C], "choice": uint8 [nseg]}"""
+    assert w16_bits.ndim == 2 and w16_bits.dtype == np.uint16 and w16_bits.flags.c_contiguous
+    K, C = w16_bits.shape
+    gs = int(group_size) if group_size and group_size > 0 else 0
+    cfgs = (_TableCfg * len(tables))()
+    for t, values in enumerate(tables):
+        cfgs[t].count = len(values)
+        for i, v in enumerate(values):
+            cfgs[t].values[i] = v
+    L = gs if gs > 0 else C
+    out = {"deq": np.empty((K, C), np.uint16), "choice": np.empty(K * C // L if L else 0, np.uint8)}
+    rc = lib().orc_search_tables(w16_bits.ctypes.data, K, C, gs, cfgs, len(tables), _ptr(out["deq"]),
+                                 _ptr(out["choice"]))
+    if rc == -2:
+        raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {K * C}")
     if rc:
         raise ValueError(f"oracle: bad argument (rc={rc})")
     return out

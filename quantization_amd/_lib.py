@@ -69,6 +69,8 @@ def lib():
         L.mq_quantize_table_workspace_bytes.argtypes = [i64, i64, ctypes.POINTER(TableCfg)]
         L.mq_quantize_table.restype = ctypes.c_int
         L.mq_quantize_table.argtypes = [vp, i32, i64, i64, ctypes.POINTER(TableCfg), ctypes.POINTER(QuantOut), vp, sz, vp]
+        L.mq_search_tables.restype = ctypes.c_int
+        L.mq_search_tables.argtypes = [vp, i64, i64, i64, ctypes.POINTER(TableCfg), i32, vp, vp, vp]
         _lib = L
     return _lib
 

@@ -386,3 +386,143 @@ extern "C" int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, i
     default: return table_launch<MQ_TABLE_MX>(p, per_tensor, out, st);
   }
 }
+
+// ================================================================================================
+// search_datatype (quant_weight.py:604-649): per segment, the first of several lists with the smallest float16
+// mean squared error.  One wave (segments up to 2048 elements) or one workgroup per segment; the segment is
+// swept once per list and once more to write the winner (the re-reads hit the cache).
+// ================================================================================================
+#define MQ_SEARCH_MAX_TABLES 8
+#define MQ_SEARCH_MAX_VALUES 32
+struct SearchParams {
+  const uint16_t* w;
+  uint16_t* deq;
+  uint8_t* choice;
+  int64_t L, nseg;
+  int32_t ntables, pad;
+  int32_t count[MQ_SEARCH_MAX_TABLES];
+  float qmax[MQ_SEARCH_MAX_TABLES];
+  float vals[MQ_SEARCH_MAX_TABLES][MQ_SEARCH_MAX_VALUES];
+  float mids[MQ_SEARCH_MAX_TABLES][MQ_SEARCH_MAX_VALUES];
+};
+
+__device__ __forceinline__ float search_scale(uint32_t amax_bits, float qmax) {
+  half_t s = (half_t)((float)h_from_bits(amax_bits) / qmax);
+  const half_t lo = h_from_bits(0x00A8u), hi = h_from_bits(0x70E2u);
+  s = s < lo ? lo : s;
+  s = s > hi ? hi : s;
+  return (float)s;
+}
+// dequantized float16 bits of one element under one list
+__device__ __forceinline__ uint32_t search_deq(const float* vals, const float* mids, int n, float v, float s) {
+  const float x = (float)(half_t)(v / s);
+  return f2h_bits(tbl_pick(vals, mids, n, x, 0) * s);
+}
+
+template <int TEAM>
+__global__ __launch_bounds__(256) void k_table_search(const SearchParams p) {
+  __shared__ float s_vals[MQ_SEARCH_MAX_TABLES][MQ_SEARCH_MAX_VALUES], s_mids[MQ_SEARCH_MAX_TABLES][MQ_SEARCH_MAX_VALUES];
+  __shared__ uint32_t red_u[4];
+  __shared__ double red_d[4];
+  for (int i = threadIdx.x; i < p.ntables * MQ_SEARCH_MAX_VALUES; i += blockDim.x) {
+    (&s_vals[0][0])[i] = (&p.vals[0][0])[i];
+    (&s_mids[0][0])[i] = (&p.mids[0][0])[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t team = TEAM == 64 ? (int64_t)blockIdx.x * 4 + wv : blockIdx.x;
+  const int64_t nteams = TEAM == 64 ? (int64_t)gridDim.x * 4 : gridDim.x;
+  const int tid = TEAM == 64 ? lane : (int)threadIdx.x;
+  for (int64_t seg = team; seg < p.nseg; seg += nteams) {
+    const uint16_t* w = p.w + seg * p.L;
+    uint32_t m = 0;
+    for (int64_t i = tid; i < p.L; i += TEAM) {
+      uint32_t a = w[i] & 0x7fffu;
+      m = a > m ? a : m;
+    }
+    m = wave_max_u32(m);
+    if (TEAM == 256) {
+      __syncthreads();
+      if (lane == 0) red_u[wv] = m;
+      __syncthreads();
+      for (int i = 0; i < 4; ++i) m = red_u[i] > m ? red_u[i] : m;
+    }
+    half_t best = (half_t)1000.0f;  // torch.full(..., 1e3, dtype=float16)
+    int pick = -1;
+    for (int t = 0; t < p.ntables; ++t) {
+      const float s = search_scale(m, p.qmax[t]);
+      // the float16 squares are multiples of 2^-24 (or inf / NaN): their float64 sum is exact
+      double acc = 0.0;
+      for (int64_t i = tid; i < p.L; i += TEAM) {
+        const half_t v = h_from_bits(w[i]);
+        const half_t d = h_from_bits(search_deq(s_vals[t], s_mids[t], p.count[t], (float)v, s));
+        const half_t e = d - v;
+        acc += (double)(float)(half_t)(e * e);
+      }
+      acc = wave_sum(acc);
+      if (TEAM == 256) {
+        __syncthreads();
+        if (lane == 0) red_d[wv] = acc;
+        __syncthreads();
+        acc = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+      }
+      // mean of a float16 tensor: float32 sum, divided in float32, rounded to float16
+      const half_t mean = (half_t)((float)acc / (float)p.L);
+      if (mean < best) { best = mean; pick = t; }  // a NaN mean never wins
+    }
+    const float s = pick >= 0 ? search_scale(m, p.qmax[pick]) : 0.0f;
+    for (int64_t i = tid; i < p.L; i += TEAM) {
+      uint32_t db = 0;
+      if (pick >= 0) db = search_deq(s_vals[pick], s_mids[pick], p.count[pick], (float)h_from_bits(w[i]), s);
+      p.deq[seg * p.L + i] = (uint16_t)db;
+    }
+    if (p.choice && tid == 0) p.choice[seg] = pick >= 0 ? (uint8_t)pick : (uint8_t)255;
+  }
+}
+
+extern "C" int mq_search_tables(const void* w_f16, int64_t rows, int64_t cols, int64_t group_size,
+                                const mq_table_cfg* tables, int32_t ntables, void* deq, uint8_t* choice,
+                                void* hip_stream) {
+  if (!tables || ntables < 1 || ntables > MQ_SEARCH_MAX_TABLES || rows < 0 || cols < 0) return MQ_ERR_ARG;
+  if (group_size > 0 && cols % group_size != 0) return MQ_ERR_GROUP;
+  SearchParams p = {};
+  for (int t = 0; t < ntables; ++t) {
+    const mq_table_cfg& c = tables[t];
+    if (c.count < 2) return MQ_ERR_ARG;
+    if (c.count > MQ_SEARCH_MAX_VALUES) return MQ_ERR_UNSUPPORTED;
+    float qmax = 0.f;
+    for (int i = 0; i < c.count; ++i) {
+      const float v = c.values[i];
+      if (!(v == v) || isinf(v) || (i > 0 && !(v > c.values[i - 1]))) return MQ_ERR_ARG;
+      if (host_round_f16(v) != v) return MQ_ERR_UNSUPPORTED;
+      qmax = fabsf(v) > qmax ? fabsf(v) : qmax;
+      p.vals[t][i] = v;
+    }
+    if (!(qmax > 0.f)) return MQ_ERR_ARG;
+    for (int i = 0; i + 1 < c.count; ++i)
+      p.mids[t][i] = host_round_f16((float)(((double)c.values[i] + (double)c.values[i + 1]) / 2.0));
+    p.count[t] = c.count;
+    p.qmax[t] = qmax;
+  }
+  const int64_t n = rows * cols;
+  if (n == 0) return MQ_OK;
+  if (!w_f16 || !deq) return MQ_ERR_ARG;
+  if (!tbl_aligned(w_f16, 2) || !tbl_aligned(deq, 2)) return MQ_ERR_ALIGN;
+  p.w = static_cast<const uint16_t*>(w_f16);
+  p.deq = static_cast<uint16_t*>(deq);
+  p.choice = choice;
+  p.L = group_size > 0 ? group_size : cols;
+  p.nseg = n / p.L;
+  p.ntables = ntables;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  if (p.L <= 2048) {
+    int64_t blocks = (p.nseg + 3) / 4;
+    if (blocks > kTblMaxGrid) blocks = kTblMaxGrid;
+    hipLaunchKernelGGL((k_table_search<64>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  } else {
+    int64_t blocks = p.nseg < kTblMaxGrid ? p.nseg : kTblMaxGrid;
+    hipLaunchKernelGGL((k_table_search<256>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}

@@ -345,3 +345,48 @@ def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_d
                                   ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     return res
+
+
+# search_datatype's candidate lists per (bit width, name) -- quant_weight.py:606-625
+MIXED_LISTS = {
+    (3, "mixed_bitmod"): ["fp3_er_pos", "fp3_er_neg", "fp3_ea_pos", "fp3_ea_neg"],
+    (3, "mixed_er"): ["fp3_er_pos", "fp3_er_neg"],
+    (3, "mixed_ea"): ["fp3_ea_pos", "fp3_ea_neg"],
+    (3, "mixed_ant"): ["int3", "fp3"],
+    (4, "mixed_bitmod"): ["fp4_er_pos", "fp4_er_neg", "fp4_ea_pos", "fp4_ea_neg"],
+    (4, "mixed_er"): ["fp4_er_pos", "fp4_er_neg"],
+    (4, "mixed_ea"): ["fp4_ea_pos", "fp4_ea_neg"],
+    (4, "mixed_ant"): ["int4", "flint4"],
+}
+_SEARCH_VALUES = dict(TABLE_LISTS, int3=MX_TABLES["mx_int3"], int4=MX_TABLES["mx_int4"])
+
+
+@torch.no_grad()
+def search_tables(w: torch.Tensor, tables, group_size=None, want_choice=False):
+    """Per row (or group) of a float16 ROCm tensor [rows, cols], the first of `tables` (value lists) with the
+    smallest float16 mean squared error (mq_search_tables).  -> deq float16 [rows, cols] (, choice uint8 [nseg])."""
+    if w.dtype != torch.float16:
+        raise NotImplementedError("the datatype search follows the reference's float16 arithmetic: pass a "
+                                  "float16 weight")
+    if not w.is_cuda:
+        raise RuntimeError("search_tables() expects a ROCm device tensor")
+    rows, cols = w.shape
+    gs = int(group_size) if group_size and group_size > 0 else 0
+    if gs > 0 and cols % gs:
+        raise RuntimeError(f"shape '[{rows}, {cols // gs}, {gs}]' is invalid for input of size {rows * cols}")
+    cfgs = (_lib.TableCfg * len(tables))()
+    for t, values in enumerate(tables):
+        if not 2 <= len(values) <= 32:
+            raise ValueError("the datatype search takes lists of 2 .. 32 values")
+        cfgs[t].count = len(values)
+        for i, v in enumerate(values):
+            cfgs[t].values[i] = v
+    w2 = w.contiguous()
+    deq = torch.empty_like(w2)
+    L = gs if gs > 0 else cols
+    choice = torch.empty(rows * cols // L if L else 0, dtype=torch.uint8, device=w.device) if want_choice else None
+    with torch.cuda.device(w.device):
+        st = _lib.lib().mq_search_tables(w2.data_ptr(), rows, cols, gs, cfgs, len(tables), deq.data_ptr(),
+                                         _ptr(choice), torch.cuda.current_stream(w.device).cuda_stream)
+    _lib.check(st)
+    return (deq, choice) if want_choice else deq

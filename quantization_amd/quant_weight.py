@@ -12,7 +12,7 @@ reference, each per-tensor (group_size == -1), per-channel (None / 0 / other neg
     quant_datatype (tables with subnormals: per-element path);
   * the irregular lists (fp3, flint4, flint5, the *_er_* / *_ea_* variants), fp8_e5m2's float32 path and MX
     (quant_mx) through the explicit-table kernel (mq_quantize_table).
-The mixed-datatype search (search_datatype) is not implemented and raises NotImplementedError.
+search_datatype (the mixed-datatype search) runs on float16 weights (mq_search_tables).
 """
 from typing import Optional
 
@@ -21,8 +21,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .fused import (LUT_FORMATS, MX_TABLES, TABLE_LISTS, quantize, quantize_batch, quantize_table,
-                    require_device)
+from .fused import (LUT_FORMATS, MIXED_LISTS, MX_TABLES, TABLE_LISTS, _SEARCH_VALUES, quantize, quantize_batch,
+                    quantize_table, require_device, search_tables)
 
 # names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
 # ValueError / AssertionError behaviour for unknown names
@@ -119,6 +119,21 @@ def quant_mx(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: int = 32)
     dev = w_fp16.device
     res = quantize_table(require_device(w_fp16), MX_TABLES[datatype], _lib.TABLE_MX, group_size)
     return res.deq.reshape(K, C).to(dev)
+
+
+@torch.no_grad()
+def search_datatype(w_fp16, wq_bits: int = 4, datatype: str = "mixed_bitmod", group_size: Optional[int] = None):
+    """Per row / group, the first of the candidate value lists with the smallest float16 mean squared error
+    (quant_weight.py:604-649).  Returns the dequantized weight in the input's dtype (float16)."""
+    if wq_bits not in (3, 4):
+        raise ValueError(f"Currently only support 3-bit and 4-bit mixed quantization, not {wq_bits}-bit")  # :627
+    if (wq_bits, datatype) not in MIXED_LISTS:
+        # (the reference falls through to an unbound datatype_list here)
+        raise ValueError(f"unknown mixed datatype {datatype!r}")
+    K, C = w_fp16.size()
+    dev = w_fp16.device
+    tables = [_SEARCH_VALUES[name] for name in MIXED_LISTS[(wq_bits, datatype)]]
+    return search_tables(require_device(w_fp16), tables, group_size).reshape(K, C).to(dev)
 
 
 @torch.no_grad()
@@ -244,7 +259,12 @@ def quant_model(model, wq_bits: Optional[int] = None, wq_datatype: Optional[str]
             m.weight.data = quant_mx(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype, group_size=32)
         return
     elif "mixed" in wq_datatype:
-        raise NotImplementedError(f"{wq_datatype}: the mixed-datatype search has no MI355X kernel yet")
+        print(f"Applying mixed datatype quantization with bits: {wq_bits}, datatype: {wq_datatype}, "
+              f"group size: {wq_groupsize}")
+        for _, m in _linears(model):
+            m.weight.data = search_datatype(m.weight.data, wq_bits=wq_bits, datatype=wq_datatype,
+                                            group_size=wq_groupsize)
+        return
     elif "fp" in wq_datatype:
         print(f"Applying floating-point datatype quantization with bits: {wq_bits}, group size: {wq_groupsize}")
         if wq_datatype in TABLE_LISTS:

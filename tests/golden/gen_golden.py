@@ -18,6 +18,7 @@ Files written:
   quant_table_formats.npz  the explicit-list formats: fp3, flint4, flint5 and the *_er_* / *_ea_* lists
                         (_fp_quant_meta + quant_datatype), fp8_e5m2 (float32 results) and quant_mx; small inputs,
                         non-finite inputs, and all float16 patterns for a subset
+  quant_search.npz      search_datatype (mixed_bitmod / mixed_er / mixed_ea / mixed_ant, 3 and 4 bits) on float16 inputs
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
@@ -286,6 +287,28 @@ def gen_more_formats():
     print("quant_more_formats.npz", len(arrays), "arrays")
 
 
+MIXED = ["mixed_bitmod", "mixed_er", "mixed_ea", "mixed_ant"]
+
+
+def gen_search():
+    gen = torch.Generator().manual_seed(13)
+    torch.manual_seed(13)
+    arrays = {}
+    inputs = {name: w.half() for name, w in distributions(8, 512, gen)
+              if name in ("normal", "heavy", "zerorows", "student_t", "tiny", "big", "outlier")}
+    inputs["normal_wide"] = (torch.randn(12, 4096, generator=gen) * 0.02).half()
+    for name, w in inputs.items():
+        arrays[f"in/{name}"] = bits16(w)
+        for wq_bits in (3, 4):
+            for kind in MIXED:
+                for gs in (None, 64):
+                    d = qw.search_datatype(w, wq_bits=wq_bits, datatype=kind, group_size=gs)
+                    assert d.dtype == torch.float16 and d.shape == w.shape
+                    arrays[f"out/{name}/{wq_bits}/{kind}/{gs_key(gs)}"] = bits16(d)
+    np.savez_compressed(os.path.join(HERE, "quant_search.npz"), **arrays)
+    print("quant_search.npz", len(arrays), "arrays")
+
+
 def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -356,6 +379,9 @@ if __name__ == "__main__":
         gen_lut_tables()
         gen_more_formats()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "search":
+        gen_search()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tables":  # only the explicit-list formats
         gen_lut_tables()
         gen_table_formats()
@@ -363,6 +389,7 @@ if __name__ == "__main__":
     gen_lut_tables()
     gen_more_formats()
     gen_table_formats()
+    gen_search()
     gen_quant_small()
     gen_exhaustive()
     gen_lut_domain()

@@ -98,3 +98,15 @@ def same_values(got, want):
         return bool(np.array_equal(gn, wn) and np.array_equal(got[~gn], want[~wn]))
     gn, wn = np.isnan(got), np.isnan(want)
     return bool(np.array_equal(gn, wn) and np.array_equal(got[~gn].view(np.uint32), want[~wn].view(np.uint32)))
+
+
+def search_cases():
+    """-> list of (input name, float16 bits, wq_bits, mixed name, group size, expected deq bits) of
+    quant_search.npz (the reference's search_datatype)."""
+    z = npz("quant_search.npz")
+    out = []
+    for k in sorted(z):
+        if k.startswith("out/"):
+            _, name, bits, kind, gk = k.split("/")
+            out.append((name, z[f"in/{name}"], int(bits), kind, None if gk == "none" else int(gk), z[k]))
+    return out

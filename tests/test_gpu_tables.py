@@ -99,6 +99,27 @@ def test_table_vs_oracle_and_error_outputs(qa, oracle, shape, gs):
     np.testing.assert_allclose(res.totals.cpu().numpy(), [sq.sum(), np.abs(err).astype(np.float64).sum()], rtol=1e-12)
 
 
+def test_golden_search_datatype(qa, oracle):
+    from quantization_amd import fused
+    qw = qa.quant_weight
+    cases = gu.search_cases()
+    assert len(cases) == 128
+    for name, arr, bits, kind, gs, exp in cases:
+        w = to_dev(arr, name + ".f16")
+        d = qw.search_datatype(w, wq_bits=bits, datatype=kind, group_size=gs)
+        assert d.dtype == torch.float16 and d.shape == w.shape
+        assert gu.same_values(bits16(d), exp), (name, bits, kind, gs)
+    # the chosen list per segment, and rows longer than a wave's share, against the oracle
+    torch.manual_seed(5)
+    w = (torch.randn(6, 8192) * 0.02).half()
+    tables = [fused._SEARCH_VALUES[n] for n in fused.MIXED_LISTS[(4, "mixed_bitmod")]]
+    for gs in (None, 128):
+        exp = oracle.search_tables(w.numpy().view(np.uint16), tables, gs)
+        d, choice = fused.search_tables(w.cuda(), tables, gs, want_choice=True)
+        assert np.array_equal(bits16(d), exp["deq"]) and np.array_equal(choice.cpu().numpy(), exp["choice"])
+        assert len(set(exp["choice"].tolist())) > 1
+
+
 def test_table_errors_and_model_routes(qa):
     import torch.nn as nn
     from quantization_amd import _lib, fused
@@ -133,3 +154,13 @@ def test_table_errors_and_model_routes(qa):
     assert model[0].weight.dtype == torch.float32 and model[0].weight_q.dtype == torch.float32
     with pytest.raises(ValueError):
         qw.quant_model(nn.Sequential(nn.Linear(8, 8)).half().cuda(), 4, "flint4", None)   # as in the reference
+    with pytest.raises(ValueError):
+        qw.search_datatype(w, 5, "mixed_er", None)
+    with pytest.raises(NotImplementedError):
+        qw.search_datatype(w.float(), 4, "mixed_er", None)
+    model = nn.Sequential(nn.Linear(128, 64)).half().cuda()
+    w0 = model[0].weight.data.clone()
+    qw.quant_model(model, 3, "mixed_ant", 32)
+    assert type(model[0]) is nn.Linear
+    assert torch.equal(model[0].weight.data.view(torch.int16),
+                       qw.search_datatype(w0, 3, "mixed_ant", 32).view(torch.int16))

@@ -140,6 +140,17 @@ def test_quant_mx(oracle, bits, fmt):
         assert gu.same_values(out["deq"], exp["deq"]), (name, gs)
 
 
+def test_search_datatype(oracle):
+    """search_datatype: per row / group the first candidate list with the smallest float16 mean squared error."""
+    from quantization_amd import fused
+    cases = gu.search_cases()
+    assert len(cases) == 128
+    for name, w, bits, kind, gs, exp in cases:
+        tables = [fused._SEARCH_VALUES[n] for n in fused.MIXED_LISTS[(bits, kind)]]
+        out = oracle.search_tables(w, tables, gs)
+        assert gu.same_values(out["deq"], exp), (name, bits, kind, gs)
+
+
 @pytest.mark.parametrize("fmt", ["int4", "int4_asym"])
 def test_four_bit_int(oracle, fmt):
     for name, w, gs, exp in gu.more_cases(fmt + ".int"):
