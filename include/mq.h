@@ -265,6 +265,26 @@ int mq_bucketize_f16(const void* abs_err_f16, int64_t n, const double* bins_host
 int mq_compare_formats_f16(const void* w_f16, const void* const* q_f16, int32_t nfmt, int64_t n,
                            uint16_t threshold_f16_bits, uint8_t* flags, void* min_err_f16, void* hip_stream);
 
+/*
+ * The scans behind the reference's histograms (np.histogram / plt.hist): the 200-bin weight histogram over a
+ * global range found in a first pass (plot_matmul_weight_rev0.py:51-101, :221-238), the 200-bin |error|
+ * histograms (elwise_error/onnx_error_cli.py:208-215, MSE&P99/quant_error_single_weight.py:81) and the 50-bin
+ * per-vector MSE histograms (MSE&P99/plot.py:81-90).  x: device array of n float16 / float32 / float64 values.
+ *
+ * mq_minmax: out[0] = min, out[1] = max as float64 (device; NaN when x holds a NaN, like np.min / np.max);
+ * with merge != 0 the previous contents of out are folded in (a running range over several arrays).
+ * mq_histogram: counts[i] += #{ edges[i] <= v < edges[i+1] }, the last bin closed on the right, values outside
+ * [edges[0], edges[nbins]] dropped -- np.histogram's rule; with numpy's own edges (np.histogram_bin_edges /
+ * np.linspace, computed by the caller) the counts equal numpy's.  edges: DEVICE array of nbins + 1 ascending
+ * float64 values, nbins <= 4096; counts: device int64 [nbins], accumulated into (zero it first; several arrays
+ * may be added into one histogram).
+ */
+size_t mq_minmax_workspace_bytes(void);
+int mq_minmax(const void* x, int32_t dtype, int64_t n, int32_t merge, double* out, void* workspace,
+              size_t workspace_bytes, void* hip_stream);
+int mq_histogram(const void* x, int32_t dtype, int64_t n, const double* edges, int32_t nbins, int64_t* counts,
+                 void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,11 @@ def _bind():
     L.mq_bucketize_f16.argtypes = [vp, i64, ctypes.POINTER(ctypes.c_double), i32, vp, vp]
     L.mq_compare_formats_f16.restype = ctypes.c_int
     L.mq_compare_formats_f16.argtypes = [vp, ctypes.POINTER(vp), i32, i64, ctypes.c_uint16, vp, vp, vp]
+    L.mq_minmax_workspace_bytes.restype = sz
+    L.mq_minmax.restype = ctypes.c_int
+    L.mq_minmax.argtypes = [vp, i32, i64, i32, vp, vp, sz, vp]
+    L.mq_histogram.restype = ctypes.c_int
+    L.mq_histogram.argtypes = [vp, i32, i64, vp, i32, vp, vp]
     L._err_bound = True
     return L
 
@@ -331,3 +336,95 @@ def to_ranges(mask: torch.Tensor) -> List[tuple]:
     starts = torch.nonzero(d == 1).reshape(-1)
     ends = torch.nonzero(d == -1).reshape(-1)
     return list(zip(starts.tolist(), (ends - starts).tolist()))
+
+
+# --------------------------------------------------------------------------- histograms (plot feeders)
+
+@torch.no_grad()
+def minmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(min, max) of a float16 / float32 / float64 device tensor as a float64 device tensor [2] (NaN when x
+    holds one, like np.min / np.max).  Passing the result of an earlier call as `out` folds it in: the running
+    global range of plot_matmul_weight_rev0.py:53-73."""
+    x = require_device(x)
+    if x.dtype not in _DT:
+        raise ValueError("minmax() takes float16, float32 or float64")
+    x = x.contiguous().reshape(-1)
+    if x.numel() == 0 and out is None:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    L = _bind()
+    merge = out is not None
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        ws, stream = workspace(x.device, L.mq_minmax_workspace_bytes())
+        st = L.mq_minmax(x.data_ptr(), _DT[x.dtype], x.numel(), int(merge), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                         stream.cuda_stream)
+    _lib.check(st)
+    return out
+
+
+def _np_dtype(t: torch.Tensor):
+    # the reference widens float16 initializers to float32 before every histogram (proto_to_array)
+    return np.float64 if t.dtype == torch.float64 else np.float32
+
+
+@torch.no_grad()
+def histogram(x: torch.Tensor, bins=10, range=None, counts: Optional[torch.Tensor] = None):
+    """np.histogram(x, bins, range) for a device tensor: (counts int64 device tensor [nbins], edges ndarray).
+
+    bins: an int (uniform bins over `range`, default the array's own min / max -- found by a first scan, as
+    plt.hist(data, bins=200) does in onnx_error_cli.py:211 and quant_error_single_weight.py:81, :122) or an
+    ascending edge array (plot_matmul_weight_rev0.py:98).  The edges are numpy's own (np.histogram_bin_edges
+    on the two extreme values, in the array's dtype; float16 counts as its float32 widening); the device
+    decides every count by np.histogram's comparison rule, so the counts equal numpy's.  `counts` (int64 [nbins])
+    is accumulated into when given."""
+    x = require_device(x)
+    if x.dtype not in _DT:
+        raise ValueError("histogram() takes float16, float32 or float64")
+    x = x.contiguous().reshape(-1)
+    if np.ndim(bins) == 0:
+        if range is None and x.numel():
+            lo, hi = minmax(x).tolist()
+            if not (np.isfinite(lo) and np.isfinite(hi)):
+                raise ValueError(f"autodetected range of [{lo}, {hi}] is not finite")  # numpy's own check
+            ends = np.array([lo, hi], dtype=_np_dtype(x))
+        else:
+            ends = np.array([], dtype=_np_dtype(x))
+        edges = np.histogram_bin_edges(ends, bins=bins, range=range)
+    else:
+        edges = np.asarray(bins)
+        if edges.ndim != 1 or edges.size < 2 or np.any(edges[:-1] > edges[1:]):
+            raise ValueError("`bins` must be 1d and increase monotonically")
+    nbins = edges.size - 1
+    if nbins > 4096:
+        raise ValueError("at most 4096 bins")
+    if counts is None:
+        counts = torch.zeros(nbins, dtype=torch.int64, device=x.device)
+    elif counts.shape != (nbins,) or counts.dtype != torch.int64 or not counts.is_contiguous():
+        raise ValueError("counts must be a contiguous int64 tensor with one entry per bin")
+    L = _bind()
+    dev_edges = torch.from_numpy(edges.astype(np.float64)).to(x.device)
+    with torch.cuda.device(x.device):
+        st = L.mq_histogram(x.data_ptr(), _DT[x.dtype], x.numel(), dev_edges.data_ptr(), nbins, counts.data_ptr(),
+                            torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(st)
+    return counts, edges
+
+
+@torch.no_grad()
+def weight_histogram(tensors: Sequence[torch.Tensor], bins: int = 200):
+    """The two-pass histogram over all weights of a model (plot_matmul_weight_rev0.py:51-101, :221-238): global
+    min / max first, np.linspace(gmin, gmax, bins + 1) as edges, then the counts of every tensor added up.
+    -> (counts int64 device tensor, edges ndarray)."""
+    tensors = [require_device(t) for t in tensors]
+    if not tensors:
+        raise ValueError("weight_histogram() needs at least one tensor")
+    rng = None
+    for t in tensors:
+        rng = minmax(t, rng)
+    gmin, gmax = (np.float32(v) for v in rng.tolist())   # the script widens every initializer to float32
+    edges = np.linspace(gmin, gmax, bins + 1)
+    counts = None
+    for t in tensors:
+        counts, _ = histogram(t, edges, counts=counts)
+    return counts, edges
