@@ -130,20 +130,42 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_histogram(const T* x, int64_t n, const double* edges, int nbins, int copies,
                                                    unsigned long long* counts) {
   extern __shared__ double hist_lds[];
+  __shared__ uint32_t s_dev;
   double* s_e = hist_lds;
   uint32_t* s_c = reinterpret_cast<uint32_t*>(hist_lds + nbins + 1);
+  if (threadIdx.x == 0) s_dev = 0u;
   for (int i = threadIdx.x; i <= nbins; i += blockDim.x) s_e[i] = edges[i];
   for (int i = threadIdx.x; i < nbins * copies; i += blockDim.x) s_c[i] = 0u;
   __syncthreads();
   const double e0 = s_e[0], eN = s_e[nbins];
+  const double width = (eN - e0) / (double)nbins;
   const double inv = (double)nbins / (eN - e0);  // first guess of the bin; inf / NaN guesses are clamped below
+  // How far, in bin widths, the edges are from the uniform grid e0 + i * width (np.linspace edges: a few 1e-6
+  // for float32 edges).  A value whose position g = (v - e0) / width is farther than that (plus the rounding of
+  // g itself) from an integer lies in bin floor(g) for certain; only the others are compared with the edges.
+  // Non-uniform edges give a margin >= 0.5: every value is compared.
+  {
+    float dev = 0.f;
+    for (int i = threadIdx.x; i <= nbins; i += blockDim.x) {
+      double d = __builtin_fabs(s_e[i] - (e0 + (double)i * width)) * inv;
+      float f = d < 1.0 ? (float)d : 1.0f;  // (NaN -> 1)
+      f = f == f ? f : 1.0f;
+      dev = f > dev ? f : dev;
+    }
+    atomicMax(&s_dev, f_bits(dev));  // non-negative floats order like their bits
+  }
+  __syncthreads();
+  const double margin = (double)f_from_bits(s_dev) * 1.0001 + 1e-9;
   uint32_t* mine = s_c + (copies > 1 ? (int)(threadIdx.x >> 6) * nbins : 0);
   for_each_elem(x, n, [&](double v) {
     if (!(v >= e0 && v <= eN)) return;
-    double g = (v - e0) * inv;
+    const double g = (v - e0) * inv;
     int idx = g >= 0.0 && g < (double)nbins ? (int)g : (g >= (double)nbins ? nbins - 1 : 0);
-    while (idx > 0 && v < s_e[idx]) --idx;
-    while (idx < nbins - 1 && v >= s_e[idx + 1]) ++idx;
+    const double frac = g - (double)idx;
+    if (!(frac > margin && frac < 1.0 - margin)) {
+      while (idx > 0 && v < s_e[idx]) --idx;
+      while (idx < nbins - 1 && v >= s_e[idx + 1]) ++idx;
+    }
     atomicAdd(&mine[idx], 1u);
   });
   __syncthreads();
