@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the quantize -> dequantize -> error hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|llama8b|tinyllama]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|tinyllama|llama8b|llama70b]
+                    [--dist normal|student_t]
 
 For N > 1 the driver starts one rank per GPU with torch.distributed.run; every rank processes its own
 copy of the workload (weak scaling: the units are independent weight tensors, no data-path collective)
@@ -13,6 +14,12 @@ element-wise absolute-error dump, plus per-group and per-tensor squared-error su
 P99 of the per-group MSE vector and the exact P99 of the absolute error.  A step is one
 pass over a batch of 16 distinct matrices (512 MiB of weights, 5.4 GB of outputs -- more than the
 256 MiB Infinity Cache, so inputs come from HBM) x 3 group sizes = 48 tensor passes in 3 batched launches.
+
+Other workloads (BASELINE.json configs[0], [2], [3], [4]; not the headline line): "tinyllama" / "llama8b" --
+all linear weights of that shape list, int8-sym per-channel, statistics only; "c3" -- TinyLlama shapes, int8-sym /
+fp8_e4m3 / fp8_e3m4 per-channel dequantized + the element-wise best-format masks of elwise_error/compare.py;
+"llama70b" -- one GPU's eighth of the Llama-3-70B linear layers (10 decoder layers, 17 GB bf16), int8 sym / asym,
+fp8_e4m3, fp8_e3m4 x {per-channel, g = 32 / 64 / 128}, statistics only.
 
 One JSON line is printed by rank 0.
 """
@@ -38,6 +45,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 TINYLLAMA = [(2048, 2048)] * 2 + [(256, 2048)] * 2 + [(5632, 2048)] * 2 + [(2048, 5632)]
 LLAMA8B = [(4096, 4096)] * 2 + [(1024, 4096)] * 2 + [(14336, 4096)] * 2 + [(4096, 14336)]
+LLAMA70B = [(8192, 8192)] * 2 + [(1024, 8192)] * 2 + [(28672, 8192)] * 2 + [(8192, 28672)]
 
 
 def model_shapes(per_layer, layers, head):
@@ -66,26 +74,58 @@ class Workload:
     """Passes are grouped into batches of same-shaped tensors: one fused launch (per 32 tensors) quantizes a
     whole batch, one set of select launches takes all its P99s."""
 
-    def __init__(self, name, device, rank):
+    def __init__(self, name, device, rank, dist_name="normal"):
         self.name = name
         g = torch.Generator(device=device)
+
+        def draw(shape, dtype):
+            """N(0, 0.02^2), or Student-t (3 degrees of freedom) scaled by 0.02: the heavy-tailed case."""
+            x = torch.randn(*shape, generator=g, device=device)
+            if dist_name == "student_t":
+                chi = torch.zeros_like(x)
+                for _ in range(3):
+                    chi += torch.randn(*shape, generator=g, device=device) ** 2
+                x = x / torch.sqrt(chi / 3)
+            return (x * 0.02).to(dtype)
+
+        self.compare = None
         self.batches = []  # (stacked weights [B, rows, cols], fmt, datatype, gs, outputs dict)
         self.results = {}
         if name == "c2":
-            self.desc = ("16x 4096x4096 fp16 N(0,0.02^2), int8-asym g=32/64/128: deq + codes + scale + zp + "
+            self.desc = (f"16x 4096x4096 fp16 {dist_name} (scale 0.02), int8-asym g=32/64/128: deq + codes + scale + zp + "
                          "abs-err(f32) dump + per-group/tensor MSE + exact P99 of |err| and of the per-group MSE")
             outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True, totals=True)
             g.manual_seed(1000 * rank)
-            w = (torch.randn(16, 4096, 4096, generator=g, device=device) * 0.02).half()
+            w = draw((16, 4096, 4096), torch.float16)
             for gs in (32, 64, 128):
                 self.batches.append((w, _lib.INT_ASYM, None, gs, outs))
         else:
-            shapes = (model_shapes(TINYLLAMA, 22, (32000, 2048)) if name == "tinyllama"
-                      else model_shapes(LLAMA8B, 32, (128256, 4096)))
-            dt = torch.float16 if name == "tinyllama" else torch.bfloat16
-            self.desc = (f"{name}-shaped random-init {str(dt).split('.')[-1]} linear weights ({len(shapes)} tensors), "
-                         "int8-sym per-channel, stats only (per-row/tensor MSE, sum|err|, exact P99 of the per-row MSE)")
-            outs = dict(deq=False, codes=False, scale=True, abs_err=None, seg_sse=True, totals=True)
+            if name in ("tinyllama", "c3"):
+                shapes, dt = model_shapes(TINYLLAMA, 22, (32000, 2048)), torch.float16
+            elif name == "llama8b":
+                shapes, dt = model_shapes(LLAMA8B, 32, (128256, 4096)), torch.bfloat16
+            else:   # one GPU's share of the 80 decoder layers (the 561-tensor model split over 8 GPUs)
+                shapes, dt = LLAMA70B * 10, torch.bfloat16
+            stats = dict(deq=False, codes=False, scale=True, abs_err=None, seg_sse=True, totals=True)
+            if name == "c3":
+                passes = [(_lib.INT_SYM, None, None), (_lib.LUT_FP, "fp8_e4m3", None), (_lib.LUT_FP, "fp8_e3m4", None)]
+                outs = dict(deq=True, codes=False, scale=False, abs_err=None, seg_sse=False, totals=True)
+                self.compare = []
+                self.desc = (f"TinyLlama-shaped {dist_name} fp16 linear weights ({len(shapes)} tensors): int8-sym, fp8_e4m3, "
+                             "fp8_e3m4 per-channel dequantized weights + tensor MSE, then the element-wise best-format / "
+                             "outlier masks of compare.py")
+            elif name == "llama70b":
+                passes = [(f, d, gs) for f, d in ((_lib.INT_SYM, None), (_lib.INT_ASYM, None), (_lib.LUT_FP, "fp8_e4m3"),
+                                                  (_lib.LUT_FP, "fp8_e3m4")) for gs in (None, 32, 64, 128)]
+                outs = stats
+                self.desc = (f"1/8 of Llama-3-70B's linear layers ({len(shapes)} tensors, bf16 {dist_name}): int8 sym / asym, "
+                             "fp8_e4m3, fp8_e3m4 x per-channel / g=32 / 64 / 128, stats only (per-vector/tensor MSE, "
+                             "sum|err|, exact P99 of the per-vector MSE)")
+            else:
+                passes = [(_lib.INT_SYM, None, None)]
+                outs = stats
+                self.desc = (f"{name}-shaped random-init {str(dt).split('.')[-1]} linear weights ({len(shapes)} tensors), "
+                             "int8-sym per-channel, stats only (per-row/tensor MSE, sum|err|, exact P99 of the per-row MSE)")
             groups = {}
             for sh in shapes:
                 groups[sh] = groups.get(sh, 0) + 1
@@ -93,11 +133,17 @@ class Workload:
                 for lo in range(0, cnt, 32):
                     b = min(32, cnt - lo)
                     g.manual_seed(1000 * rank + 17 * k + lo)
-                    w = (torch.randn(b, r, c, generator=g, device=device) * 0.02).to(dt)
-                    self.batches.append((w, _lib.INT_SYM, None, None, outs))
+                    w = draw((b, r, c), dt)
+                    first = len(self.batches)
+                    for fmt, table, gs in passes:
+                        self.batches.append((w, fmt, table, gs, outs))
+                    if self.compare is not None:
+                        self.compare.append((w, list(range(first, first + len(passes))),
+                                             torch.empty(w.shape, dtype=torch.uint8, device=device)))
         self.kernel_desc = ("fused quantize pass (k_quant_team/wave/block: one launch per batch of same-shaped tensors"
                             + (", feeding the P99 selection)" if name == "c2" else ")"))
         self.tensors = sum(w.shape[0] for w, *_ in self.batches)
+        # weight bytes of a step: every pass over a tensor counts (a sweep quantizes the same weights per format)
         self.weight_bytes = sum(w.numel() * w.element_size() for w, *_ in self.batches)
         self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f, gs, o)
                               for w, f, _, gs, o in self.batches)
@@ -133,6 +179,13 @@ class Workload:
             results.append(res)
             row += w.shape[0]
         rec = self.record
+        if self.compare is not None:
+            # compare.py:99-125 on the three dequantized stacks of every batch: flags per element
+            from quantization_amd.error_metrics import compare_formats
+            for w, idxs, flags in self.compare:
+                compare_formats(w, [results[i].deq for i in idxs], 0.02, out=flags)
+            rec[:, 0:2] = self.totals
+            return [rec]
         rec[:, 0:2] = self.totals
         # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
         rec[:, 2] = self.totals[:, 0] / self.numel
@@ -185,7 +238,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "tinyllama", "llama8b"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "tinyllama", "llama8b", "llama70b"])
+    ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -208,7 +262,7 @@ def main():
     device = torch.device("cuda", torch.cuda.current_device())
     _lib.lib()
 
-    wl = Workload(args.workload, device, rank)
+    wl = Workload(args.workload, device, rank, args.dist)
     gathered = torch.zeros(world * wl.tensors, 5, dtype=torch.float64, device=device) if world > 1 else None
 
     def one_step():

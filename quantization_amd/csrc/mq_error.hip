@@ -269,6 +269,76 @@ __global__ __launch_bounds__(256) void k_compare(CompareParams p) {
   }
 }
 
+// The same for 8 consecutive elements per lane (16-byte loads, packed float16 subtraction, 16-bit integer
+// min / max / compares on the sign-cleared bits: for non-negative float16 values, and NaN above 0x7c00, the
+// integer order is the float order).
+__device__ __forceinline__ uint32_t err_pk_min_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t err_pk_max_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int NF>
+__global__ __launch_bounds__(256) void k_compare_vec(CompareParams p) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nvec = p.n / 8;
+  const uint32_t thr = p.thr_bits & 0xffffu;
+  const bool thr_nan = (thr & 0x7fffu) > 0x7c00u, thr_neg = (thr & 0x8000u) != 0;
+  for (int64_t v = t0; v < nvec; v += step) {
+    const u32x4 w = reinterpret_cast<const u32x4*>(p.w)[v];
+    // (plain arrays: with ext_vector variables as the asm operands hipcc 7.2 used word 0 for every k)
+    uint32_t e[NF][4], mn[4], mx[4], mo[4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const u32x4 q = reinterpret_cast<const u32x4*>(p.q[f])[v];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h16x2 d = __builtin_bit_cast(h16x2, (uint32_t)w[k]) - __builtin_bit_cast(h16x2, (uint32_t)q[k]);
+        e[f][k] = __builtin_bit_cast(uint32_t, d) & 0x7fff7fffu;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      mn[k] = e[0][k];
+      mx[k] = e[0][k];
+#pragma unroll
+      for (int f = 1; f < NF; ++f) {
+        mn[k] = err_pk_min_u16(mn[k], e[f][k]);
+        mx[k] = err_pk_max_u16(mx[k], e[f][k]);
+      }
+    }
+    uint32_t fl[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = i >> 1, sh = (i & 1) * 16;
+      uint32_t m = (mn[k] >> sh) & 0xffffu;
+      const bool nan = ((mx[k] >> sh) & 0xffffu) > 0x7c00u;
+      // m > thr as float16 values (m >= +0): false for a NaN threshold, true for any negative one except -0 vs 0
+      const bool out = thr_nan ? false : (thr_neg ? ((thr & 0x7fffu) != 0u || m != 0u) : m > thr);
+      uint32_t f8 = out ? 0x80u : 0u;
+      if (!out) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) f8 |= (((e[f][k] >> sh) & 0xffffu) == m) ? (1u << f) : 0u;
+      }
+      if (nan) { f8 = 0u; m = 0x7e00u; }  // numpy's min propagates NaN; every comparison with it is false
+      fl[i >> 2] |= f8 << ((i & 3) * 8);
+      if (i & 1) mo[k] |= m << 16; else mo[k] = m;
+    }
+    reinterpret_cast<u32x2*>(p.flags)[v] = u32x2{fl[0], fl[1]};
+    if (p.min_err) reinterpret_cast<u32x4*>(p.min_err)[v] = u32x4{mo[0], mo[1], mo[2], mo[3]};
+  }
+}
+
+template <int NF>
+static void launch_compare_vec(const CompareParams& p, hipStream_t st) {
+  int64_t blocks = (p.n / 8 + 255) / 256;
+  hipLaunchKernelGGL(k_compare_vec<NF>, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, st, p);
+}
+
 // ================================================================================================
 static const int kErrMaxGrid = MQ_MAX_GRID;
 
@@ -378,9 +448,33 @@ extern "C" int mq_compare_formats_f16(const void* w_f16, const void* const* q_f1
   p.thr_bits = threshold_f16_bits;
   p.flags = flags;
   p.min_err = static_cast<uint16_t*>(min_err_f16);
-  int64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(k_compare, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0,
-                     static_cast<hipStream_t>(hip_stream), p);
-  MQ_HIP(hipGetLastError());
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  auto al = [](const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
+  bool vec_ok = n >= 8 && al(w_f16, 16) && al(flags, 8) && al(min_err_f16, 16);
+  for (int i = 0; i < nfmt; ++i) vec_ok = vec_ok && al(q_f16[i], 16);
+  int64_t done = 0;
+  if (vec_ok) {
+    switch (nfmt) {
+      case 1: launch_compare_vec<1>(p, st); break;
+      case 2: launch_compare_vec<2>(p, st); break;
+      case 3: launch_compare_vec<3>(p, st); break;
+      case 4: launch_compare_vec<4>(p, st); break;
+      case 5: launch_compare_vec<5>(p, st); break;
+      case 6: launch_compare_vec<6>(p, st); break;
+      default: launch_compare_vec<7>(p, st); break;
+    }
+    MQ_HIP(hipGetLastError());
+    done = n / 8 * 8;
+  }
+  if (done < n) {  // the ragged end, or everything when a pointer is not 16-byte aligned
+    p.w += done;
+    for (int i = 0; i < nfmt; ++i) p.q[i] += done;
+    p.flags += done;
+    if (p.min_err) p.min_err += done;
+    p.n = n - done;
+    int64_t blocks = (p.n + 255) / 256;
+    hipLaunchKernelGGL(k_compare, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p);
+    MQ_HIP(hipGetLastError());
+  }
   return MQ_OK;
 }

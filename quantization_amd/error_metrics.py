@@ -304,14 +304,27 @@ def bucketize(w_fp16: torch.Tensor, w_q: torch.Tensor, step: float = 0.0001, max
 
 
 @torch.no_grad()
-def compare_formats(w_fp16: torch.Tensor, w_qs: Sequence[torch.Tensor], threshold: float = 0.02):
+def compare_formats(w_fp16: torch.Tensor, w_qs: Sequence[torch.Tensor], threshold: float = 0.02,
+                    out: Optional[torch.Tensor] = None):
     """compare.py:99-125: per-format float16 |w - w_q|, element-wise minimum, outlier mask (min > threshold)
-    and per-format "is best" masks.  Returns dict(min_err float16, mask_out bool, best list of bool)."""
+    and per-format "is best" masks.  Returns dict(min_err float16, mask_out bool, best list of bool, flags).
+    With `out` (uint8, one byte per element) only the packed flags are produced, into it: bit 7 = outlier,
+    bit f = format f is best."""
     if not 1 <= len(w_qs) <= 7:
         raise ValueError("1..7 formats")
     w = require_device(w_fp16).half().contiguous().reshape(-1)
     qs = [require_device(q).half().contiguous().reshape(-1).to(w.device) for q in w_qs]
     n = w.numel()
+    if out is not None:
+        if out.dtype != torch.uint8 or out.numel() != n or not out.is_contiguous() or out.device != w.device:
+            raise ValueError("out must be a contiguous uint8 device tensor with one byte per element")
+        arr = (ctypes.c_void_p * len(qs))(*[q.data_ptr() for q in qs])
+        with torch.cuda.device(w.device):
+            st = _bind().mq_compare_formats_f16(w.data_ptr(), arr, len(qs), n, int(np.float16(threshold).view(np.uint16)),
+                                                out.data_ptr(), None,
+                                                torch.cuda.current_stream(w.device).cuda_stream)
+        _lib.check(st)
+        return {"flags": out}
     flags = torch.empty(n, dtype=torch.uint8, device=w.device)
     min_err = torch.empty(n, dtype=torch.float16, device=w.device)
     arr = (ctypes.c_void_p * len(qs))(*[q.data_ptr() for q in qs])

@@ -205,3 +205,33 @@ def test_percentile_multi_mixed_lengths(em, dtype):
     got = em.percentile_multi([torch.from_numpy(a).cuda() for a in arrs], 99).cpu().numpy()
     want = np.array([np.percentile(a, 99) for a in arrs], dtype)
     assert got.tobytes() == want.tobytes()
+
+
+def test_compare_formats_vector_and_scalar_paths(em, oracle):
+    """compare.py masks on ragged lengths, unaligned views, inf / NaN elements and odd thresholds: the 8-per-lane
+    kernel, its scalar tail and the all-scalar route against the numpy restatement."""
+    rng = np.random.default_rng(11)
+    n = 8 * 1000 + 5
+    w = (rng.standard_normal(n) * 0.02).astype(np.float16)
+    qs = [(w.astype(np.float32) + rng.standard_normal(n).astype(np.float32) * s).astype(np.float16)
+          for s in (1e-3, 2e-3, 1e-3, 5e-4, 3e-3)]
+    qs[2][::3] = qs[0][::3]                      # ties between formats
+    w[17], qs[1][40], qs[3][99] = np.nan, np.inf, -np.inf
+    qs[4][123] = np.nan
+    w[200:208] = qs[0][200:208]                  # exact zeros
+    tw, tq = torch.from_numpy(w).cuda(), [torch.from_numpy(q).cuda() for q in qs]
+    for nf in (1, 3, 5):
+        for lo in (0, 1):                        # lo = 1: views that are not 16-byte aligned
+            for thr in (0.02, 1e-3, 0.0, -0.0, -1.0, float("nan")):
+                with np.errstate(invalid="ignore"):
+                    exp = oracle.compare_formats(w[lo:], [q[lo:] for q in qs[:nf]], threshold=np.float16(thr))
+                got = em.compare_formats(tw[lo:], [q[lo:] for q in tq[:nf]], threshold=thr)
+                gm, wm = got["min_err"].cpu().numpy(), exp["min_err"]
+                assert np.array_equal(np.isnan(gm), np.isnan(wm)) and np.array_equal(gm[~np.isnan(gm)], wm[~np.isnan(wm)])
+                assert np.array_equal(got["mask_out"].cpu().numpy(), exp["mask_out"]), (nf, lo, thr)
+                for f in range(nf):
+                    assert np.array_equal(got["best"][f].cpu().numpy(), exp["best"][f]), (nf, lo, thr, f)
+    flags = torch.empty(n, dtype=torch.uint8, device="cuda")
+    r = em.compare_formats(tw, tq[:3], 0.02, out=flags)
+    assert r["flags"] is flags
+    assert torch.equal(flags, em.compare_formats(tw, tq[:3], 0.02)["flags"])
