@@ -792,9 +792,22 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
       sp = params_absmax(m, p);
     }
     double s = 0.0;
+    if (__builtin_expect(sp.slow, 0)) {
+      // The per-element path is the same for the whole segment.  It reloads its vectors (cache hits) in a rolled
+      // loop: indexing raw[] with a run-time j would move the register array to scratch memory for both paths.
+#pragma unroll 1
+      for (int j = 0; j < NV; ++j) {
+        const int v = j * tcount + tid;
+        if (v < p.vecs_per_seg) {
+          const int64_t e0 = base + (int64_t)v * 8;
+          s += quant8_slow<FMT, SEL>(p, load8_f16(p.w, p.in_dtype, e0), sp, e0, acc);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-      if (valid[j]) s += quant8<FMT, SEL>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc);
+      for (int j = 0; j < NV; ++j)
+        if (valid[j]) s += quant8_fast<FMT, SEL>(p, raw[j], sp, base + (int64_t)(j * tcount + tid) * 8, acc);
+    }
     acc_sse += s;
     if (p.seg_sse) {
       s = wave_sum(s);
