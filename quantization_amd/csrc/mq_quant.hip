@@ -23,7 +23,7 @@
 // This file must be compiled with -ffp-contract=off and without fast-math.
 //
 // The file is compiled four times (Makefile): MQ_PART 0 holds the host side and the format-independent
-// kernels; MQ_PART 1 / 2 / 3 hold the kernel instantiations of one format each (symmetric INT, asymmetric INT,
+// kernels; MQ_PART 1 / 2 / 3 / 4 hold the kernel instantiations of one format each (symmetric INT, asymmetric INT,
 // value tables) behind mq_launch_fmt<N>(), so that a clean build runs in parallel.
 #include <stdlib.h>
 
@@ -31,16 +31,20 @@
 #include "mq_sel.h"
 
 #ifndef MQ_PART
-#error "compile with -DMQ_PART=0..3 (see Makefile)"
+#error "compile with -DMQ_PART=0..4 (see Makefile)"
 #endif
+#define MQ_IS_LUT(F) ((F) == MQ_LUT_FP || (F) == MQ_LUT_FP_SUB)
 
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
 
 struct LutConst {
   uint32_t shift, half, maxb, minpos, mid;  // rounding constants in the float16 (or float32) bit domain
   // tables WITH subnormals (MQ_LUT_FP_SUB): values m * 2^(1-bias-M) below sub_lim = 2^(1-bias), then
-  // (1 + m / 2^M) * 2^(e-bias) up to sub_max; rounded per element in float64 (lut_round_sub)
+  // (1 + m / 2^M) * 2^(e-bias) up to sub_max.  Fast path: lut_round_pk_sub on the float16 bits (shift / half /
+  // maxb / minpos / mid as above, with minpos = the grid step u and mid = u / 2; elim = the float16 exponent
+  // field of sub_lim); per-element path and the float32 branch: lut_round_sub in float64.
   int32_t sub, man;
+  uint32_t elim;
   double sub_lim, sub_max;
 };
 
@@ -322,7 +326,6 @@ __device__ __forceinline__ SegP params_absmax(uint32_t amax_bits, const QuantPar
   sp.zp = (half_t)0;
   sp.slow = amax_bits >= 0x7c00u;  // inf or NaN in the segment
   if (sp.slow) finish_params(sp, clamp_scale((half_t)((float)h_from_bits(amax_bits) / p.qmax)));
-  sp.slow = sp.slow || p.lut.sub != 0;  // tables with subnormals are rounded per element
   return sp;
 }
 // mm: min in the low half, max in the high half
@@ -371,6 +374,33 @@ __device__ __forceinline__ uint32_t lut_round_pk(uint32_t xw, const LutConst& c)
   r = pk_max_u16(pk_min_u16(r, dup16(c.maxb)), dup16(c.minpos));
   uint32_t z = pk_sub_u16_sat(an, dup16(c.mid));  // nonzero iff |x| is past the 0 / minpos midpoint
   uint32_t m = pk_sub_u16(0u, pk_min_u16(z, 0x00010001u));  // 0xffff or 0 per half
+  return ((xw & 0x80008000u) | r) & m;  // zero is +0
+}
+
+// The packed rounding for a table WITH subnormals.  Below sub_lim = 2^(elim-15) the table is the uniform grid
+// m * u, u = sub_lim / 2^M: a value whose exponent field is elim - k (k = 1 .. M) keeps M - k mantissa bits,
+// i.e. the mantissa rounding above with a shift that grows by k; below u the choice is between u and 0 at
+// their midpoint (minpos = u, mid = u / 2: the same rule as for the smallest entry of a table without
+// subnormals; u is a normal float16, so every float16 subnormal input lands here).
+__device__ __forceinline__ uint32_t pk_shl_u16(uint32_t sh, uint32_t v) {
+  uint32_t r;
+  asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh), "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_shr_u16(uint32_t sh, uint32_t v) {
+  uint32_t r;
+  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh), "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t lut_round_pk_sub(uint32_t xw, const LutConst& c) {
+  uint32_t a = xw & 0x7fff7fffu;
+  uint32_t an = pk_add_u16(a, (xw >> 15) & 0x00010001u);  // a + 1 for negative x: turns '>=' into '>'
+  uint32_t k = pk_min_u16(pk_sub_u16_sat(dup16(c.elim), pk_shr_u16(dup16(10u), a)), dup16((uint32_t)c.man));
+  uint32_t one = pk_shl_u16(pk_add_u16(k, dup16(c.shift)), 0x00010001u);  // 1 << shift, per half
+  uint32_t r = pk_add_u16(an, pk_sub_u16(pk_shr_u16(0x00010001u, one), 0x00010001u)) & pk_sub_u16(0u, one);
+  r = pk_max_u16(pk_min_u16(r, dup16(c.maxb)), dup16(c.minpos));
+  uint32_t z = pk_sub_u16_sat(an, dup16(c.mid));  // nonzero iff |x| is past the 0 / u midpoint
+  uint32_t m = pk_sub_u16(0u, pk_min_u16(z, 0x00010001u));
   return ((xw & 0x80008000u) | r) & m;  // zero is +0
 }
 
@@ -487,7 +517,7 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
       cw[k] = tw;
     } else {
       // the table's zero is +0 and a nonzero quotient has the right sign already
-      uint32_t qw = lut_round_pk(as_u32(x), p.lut);
+      uint32_t qw = FMT == MQ_LUT_FP_SUB ? lut_round_pk_sub(as_u32(x), p.lut) : lut_round_pk(as_u32(x), p.lut);
       d = as_h2(qw) * as_h2(s2);
       cw[k] = qw;
     }
@@ -497,7 +527,7 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
   }
   if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
   if (p.codes) {
-    if constexpr (FMT == MQ_LUT_FP) {
+    if constexpr (MQ_IS_LUT(FMT)) {
       *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = cw;
     } else {
       if constexpr (FMT == MQ_INT_ASYM) {
@@ -552,7 +582,7 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
     }
     uint32_t db = h_bits(d);
     if (i & 1) dq[i >> 1] |= db << 16; else dq[i >> 1] = db;
-    if constexpr (FMT == MQ_LUT_FP) {
+    if constexpr (MQ_IS_LUT(FMT)) {
       if (i & 1) c16[i >> 1] |= code << 16; else c16[i >> 1] = code;
     } else {
       c8[i >> 2] |= code << (8 * (i & 3));
@@ -561,7 +591,7 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
   }
   if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
   if (p.codes) {
-    if constexpr (FMT == MQ_LUT_FP) {
+    if constexpr (MQ_IS_LUT(FMT)) {
       *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = c16;
     } else {
       u32x2 c = {c8[0], c8[1]};
@@ -928,7 +958,7 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
   const int64_t tiles = (nvec + 64 * NV - 1) / (64 * NV);
   SegP sp;
   float s32 = 0.f;
-  if (FMT == MQ_LUT_FP && p.f32_math) {
+  if (MQ_IS_LUT(FMT) && p.f32_math) {
     // scale = (rmax / qmax).clamp(1e-5, 1e4), all float32
     float s = f_from_bits(p.tred[0]) / p.qmax;
     s = s < 1e-5f ? 1e-5f : s;
@@ -955,7 +985,7 @@ __global__ __launch_bounds__(256) void k_quant_tensor(const QuantBatch b) {
     for (int j = 0; j < NV; ++j) {
       if (!valid[j]) continue;
       int64_t e0 = ((tile * NV + j) * 64 + lane) * 8;
-      if (FMT == MQ_LUT_FP && p.f32_math) {
+      if (MQ_IS_LUT(FMT) && p.f32_math) {
         float w32[8];
         load8_f32(p.w, p.in_dtype, e0, w32);
         acc_sse += quant8_lut_f32(p, w32, raw[j], s32, e0, acc);
@@ -1033,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
       }
       if (p.deq) p.deq[base + i] = (uint16_t)h_bits(d);
       if (p.codes) {
-        if (FMT == MQ_LUT_FP) static_cast<uint16_t*>(p.codes)[base + i] = (uint16_t)code;
+        if (MQ_IS_LUT(FMT)) static_cast<uint16_t*>(p.codes)[base + i] = (uint16_t)code;
         else static_cast<uint8_t*>(p.codes)[base + i] = (uint8_t)code;
       }
       float err = vf - (float)d;
@@ -1100,6 +1130,13 @@ static int ilog2_ceil(int64_t x) {
   return l;
 }
 
+// float16 bits of a non-negative value that float16 represents exactly
+static uint32_t host_f2h_exact(double v) {
+  if (v < ldexp(1.0, -14)) return (uint32_t)ldexp(v, 24);
+  int e = ilogb(v);
+  return ((uint32_t)(e + 15) << 10) | (uint32_t)ldexp(v / ldexp(1.0, e) - 1.0, 10);
+}
+
 static bool lut_consts(const mq_quant_cfg* cfg, bool f32, LutConst* c, float* lutmax) {
   const int E = cfg->exp_bits, M = cfg->man_bits, B = cfg->exp_bias;
   *c = LutConst{};
@@ -1113,6 +1150,15 @@ static bool lut_consts(const mq_quant_cfg* cfg, bool f32, LutConst* c, float* lu
     c->man = M;
     c->sub_lim = lim;
     c->sub_max = mx;
+    if (!f32) {  // constants of lut_round_pk_sub (float16 bit domain)
+      if (1 - B + 15 < 1 || 1 - B + 15 > 30) return false;
+      c->elim = (uint32_t)(1 - B + 15);
+      c->shift = (uint32_t)(10 - M);
+      c->half = 1u << (c->shift - 1);
+      c->maxb = host_f2h_exact(mx);
+      c->minpos = host_f2h_exact(u);
+      c->mid = host_f2h_exact(u / 2);
+    }
     *lutmax = (float)mx;
     return true;
   }
@@ -1209,7 +1255,7 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
 
 // One format's kernels per translation unit.
 #if MQ_PART >= 1
-#define MQ_PART_FMT (MQ_PART - 1)  // MQ_INT_SYM, MQ_INT_ASYM, MQ_LUT_FP
+#define MQ_PART_FMT (MQ_PART - 1)  // MQ_INT_SYM, MQ_INT_ASYM, MQ_LUT_FP, MQ_LUT_FP_SUB
 #define MQ_CAT2(a, b) a##b
 #define MQ_CAT(a, b) MQ_CAT2(a, b)
 void MQ_CAT(mq_launch_fmt, MQ_PART)(int sel_mode, int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds,
@@ -1224,6 +1270,7 @@ void MQ_CAT(mq_launch_fmt, MQ_PART)(int sel_mode, int scope, int nv, int threads
 void mq_launch_fmt1(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 void mq_launch_fmt2(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 void mq_launch_fmt3(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+void mq_launch_fmt4(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
 #include <vector>
@@ -1294,7 +1341,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   p.n = n;
   p.L = cfg->group_size == -1 ? n : (cfg->group_size <= 0 ? cols : cfg->group_size);
   p.nseg = n / p.L;
-  const int fmt = cfg->format == MQ_LUT_FP_SUB ? MQ_LUT_FP : cfg->format;  // same kernels, per-element rounding
+  const int fmt = cfg->format;
   if (cfg->format == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
   else if (cfg->format == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
   else if (!lut_consts(cfg, cfg->f32_math != 0, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
@@ -1318,7 +1365,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
       return MQ_ERR_ARG;
     if (!aligned(items[i].w, esz) || !aligned(o.deq, 2) || !aligned(o.scale, 2) || !aligned(o.zero_point, 2) ||
         !aligned(o.seg_sse, 8) || !aligned(o.totals, 8) || !aligned(o.abs_err, p.abs_err_f16 ? 2 : 4) ||
-        (fmt == MQ_LUT_FP && !aligned(o.codes, 2)))
+        (MQ_IS_LUT(fmt) && !aligned(o.codes, 2)))
       return MQ_ERR_ALIGN;
     vec_ok = vec_ok && aligned(items[i].w, 16) && aligned(o.deq, 16) && aligned(o.codes, 16) && aligned(o.abs_err, 16);
     BatchItem& it = b.item[i];
@@ -1411,7 +1458,8 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   switch (fmt) {
     case MQ_INT_SYM: mq_launch_fmt1(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
     case MQ_INT_ASYM: mq_launch_fmt2(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
-    default: mq_launch_fmt3(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    case MQ_LUT_FP: mq_launch_fmt3(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    default: mq_launch_fmt4(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
   }
   MQ_HIP(hipGetLastError());
   if (timed) MQ_HIP(hipEventRecord(prof_events.back(), st));
