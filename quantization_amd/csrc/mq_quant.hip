@@ -22,9 +22,9 @@
 // per-element slow path, which follows the contract literally.
 // This file must be compiled with -ffp-contract=off and without fast-math.
 //
-// The file is compiled four times (Makefile): MQ_PART 0 holds the host side and the format-independent
+// The file is compiled five times (Makefile): MQ_PART 0 holds the host side and the format-independent
 // kernels; MQ_PART 1 / 2 / 3 / 4 hold the kernel instantiations of one format each (symmetric INT, asymmetric INT,
-// value tables) behind mq_launch_fmt<N>(), so that a clean build runs in parallel.
+// value tables without / with subnormals) behind mq_launch_fmt<N>(), so that a clean build runs in parallel.
 #include <stdlib.h>
 
 #include "mq_common.h"

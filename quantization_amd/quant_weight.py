@@ -9,7 +9,7 @@ Supported on the device: symmetric / asymmetric INT with 2..8 bits and every val
 reference, each per-tensor (group_size == -1), per-channel (None / 0 / other negatives) or per-group (> 0):
   * regular minifloat grids through the fused kernels -- fp8_e4m3, fp8_e3m4, fp8_e2m5 (no subnormals: packed
     fast path), fp4, fp5 / fp5_e2m2, fp5_e3m1, fp6 / fp6_e2m3, fp6_e3m2 and the INTn lists when passed to
-    quant_datatype (tables with subnormals: per-element path);
+    quant_datatype (tables with subnormals: packed rounding with a per-element shift);
   * the irregular lists (fp3, flint4, flint5, the *_er_* / *_ea_* variants), fp8_e5m2's float32 path and MX
     (quant_mx) through the explicit-table kernel (mq_quantize_table).
 search_datatype (the mixed-datatype search) runs on float16 weights (mq_search_tables).
