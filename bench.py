@@ -156,8 +156,7 @@ class Workload:
             L = gs if gs else w.shape[2]
             lens += [L] * w.shape[0]
             counts += [w.shape[1] * w.shape[2]] * w.shape[0]
-        self.pow2 = all(L & (L - 1) == 0 for L in lens)
-        self.vec_len = torch.tensor(lens, dtype=torch.float64, device=device)
+        self.post_div = torch.tensor([L if L & (L - 1) == 0 else 1 for L in lens], dtype=torch.float64, device=device)
         self.numel = torch.tensor(counts, dtype=torch.float64, device=device)
         self.totals = torch.zeros(self.tensors, 2, dtype=torch.float64, device=device)
 
@@ -190,16 +189,14 @@ class Workload:
         # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
         rec[:, 2] = self.totals[:, 0] / self.numel
         # exact P99 of every per-vector MSE list (float64 select).  A power-of-two L divides after the select
-        # (an exponent shift commutes with it); otherwise the list is divided first, per batch.
-        if self.pow2:
-            vecs = [res.seg_sse[i] for res in results for i in range(res.seg_sse.shape[0])]
-            rec[:, 3] = percentile_multi(vecs, 99) / self.vec_len
-        else:
-            vecs = []
-            for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
-                per_vec = true_div(res.seg_sse, gs if gs else w.shape[2])   # IEEE division, as the scripts divide
-                vecs += [per_vec[i] for i in range(per_vec.shape[0])]
-            rec[:, 3] = percentile_multi(vecs, 99)
+        # (an exponent shift commutes with it); any other length divides its list first (IEEE division, as the
+        # scripts divide), per batch.
+        vecs = []
+        for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
+            L = gs if gs else w.shape[2]
+            per_vec = res.seg_sse if L & (L - 1) == 0 else true_div(res.seg_sse, L)
+            vecs += [per_vec[i] for i in range(per_vec.shape[0])]
+        rec[:, 3] = percentile_multi(vecs, 99) / self.post_div
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
         return [rec]
