@@ -36,6 +36,12 @@
 #define MQ_IS_LUT(F) ((F) == MQ_LUT_FP || (F) == MQ_LUT_FP_SUB)
 
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
+// The kernels' SEL template parameter: one of the SEL_FEED_* values, or SEL_STATS_ONLY = no selection feed and no
+// element-sized output (deq / codes / abs_err all absent: the sweeps that only want the error statistics), which
+// drops the per-vector tests of the output pointers and everything that only served the stores.
+enum { SEL_STATS_ONLY = 3 };
+#define SEL_FEEDS(S) ((S) == SEL_FEED_SAMPLE || (S) == SEL_FEED_COUNT)
+#define SEL_STORES(S) ((S) == SEL_FEED_OFF || (S) == SEL_FEED_COUNT)  // may have element-sized outputs
 
 struct LutConst {
   uint32_t shift, half, maxb, minpos, mid;  // rounding constants in the float16 (or float32) bit domain
@@ -525,26 +531,30 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
     e[2 * k] = v0 - (float)d[0];
     e[2 * k + 1] = v1 - (float)d[1];
   }
-  if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
-  if (p.codes) {
-    if constexpr (MQ_IS_LUT(FMT)) {
-      *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = cw;
-    } else {
-      if constexpr (FMT == MQ_INT_ASYM) {
-        // integers 0..255 as float16: the low byte of the bits of 1024 + q is q
-        const h16x2 k1024 = as_h2(0x64006400u);
+  if constexpr (SEL_STORES(SEL)) {
+    if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
+    if (p.codes) {
+      if constexpr (MQ_IS_LUT(FMT)) {
+        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = cw;
+      } else {
+        if constexpr (FMT == MQ_INT_ASYM) {
+          // integers 0..255 as float16: the low byte of the bits of 1024 + q is q
+          const h16x2 k1024 = as_h2(0x64006400u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cw[k] = as_u32(as_h2(cw[k]) + k1024);
+          for (int k = 0; k < 4; ++k) cw[k] = as_u32(as_h2(cw[k]) + k1024);
+        }
+        u32x2 c = {__builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u), __builtin_amdgcn_perm(cw[3], cw[2], 0x06040200u)};
+        *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
       }
-      u32x2 c = {__builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u), __builtin_amdgcn_perm(cw[3], cw[2], 0x06040200u)};
-      *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
     }
   }
   double sse = 0.0;
-  if (p.need_err) {
-    if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
+  if (!SEL_STORES(SEL) || p.need_err) {
+    if constexpr (SEL_STORES(SEL)) {
+      if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
+    }
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL != SEL_FEED_OFF) sel_feed8<SEL>(acc.sel, e, e0);
+    if constexpr (SEL_FEEDS(SEL)) sel_feed8<SEL>(acc.sel, e, e0);
   }
   return sse;
 }
@@ -589,20 +599,24 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
     }
     e[i] = vf - (float)d;
   }
-  if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
-  if (p.codes) {
-    if constexpr (MQ_IS_LUT(FMT)) {
-      *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = c16;
-    } else {
-      u32x2 c = {c8[0], c8[1]};
-      *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
+  if constexpr (SEL_STORES(SEL)) {
+    if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
+    if (p.codes) {
+      if constexpr (MQ_IS_LUT(FMT)) {
+        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = c16;
+      } else {
+        u32x2 c = {c8[0], c8[1]};
+        *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
+      }
     }
   }
   double sse = 0.0;
-  if (p.need_err) {
-    if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
+  if (!SEL_STORES(SEL) || p.need_err) {
+    if constexpr (SEL_STORES(SEL)) {
+      if (p.abs_err) store_abs_err(p, e, e0, acc.xp);
+    }
     error_sums(e, sse, acc.abs);
-    if constexpr (SEL != SEL_FEED_OFF) sel_feed8<SEL>(acc.sel, e, e0);
+    if constexpr (SEL_FEEDS(SEL)) sel_feed8<SEL>(acc.sel, e, e0);
   }
   return sse;
 }
@@ -670,7 +684,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   const int lane = threadIdx.x & 63;
   const int tl = lane & (T - 1), team = lane / T;
   constexpr int SPW = 64 / T;  // segments per wave per vector slot
@@ -743,7 +757,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
     }
   }
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_flush<SEL>(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -871,10 +885,10 @@ __global__ __launch_bounds__(256) void k_quant_wave(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, false, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_flush<SEL>(acc.sel);
 }
 
 template <int FMT, int NV, int THREADS, int SEL>
@@ -886,10 +900,10 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = (p.abs_err && !p.abs_err_f16) ? xpose + (threadIdx.x >> 6) * 512 : nullptr;
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_init<SEL>(acc.sel, p.sel_ws, sel_lds, p.sel_samples);
   row_body<FMT, NV, true, SEL>(p, lds, acc_sse, acc);
   block_partials(p, acc_sse, acc.abs, lds);
-  if constexpr (SEL != SEL_FEED_OFF) sel_feed_flush<SEL>(acc.sel);
+  if constexpr (SEL_FEEDS(SEL)) sel_feed_flush<SEL>(acc.sel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1219,7 +1233,8 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
   }
 }
 
-// SEL: SEL_FEED_OFF, or the two passes that feed a percentile selection (team scope only: rows are not fed).
+// SEL: SEL_FEED_OFF / SEL_STATS_ONLY, or the two passes that feed a percentile selection (team scope only: rows
+// are not fed).
 template <int FMT, int SEL>
 static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
                        const QuantBatch& p) {
@@ -1227,7 +1242,7 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
     launch_team<FMT, 4, SEL>(team_log2, grid, lds, st, p);
     return;
   }
-  if constexpr (SEL == SEL_FEED_OFF) {
+  if constexpr (!SEL_FEEDS(SEL)) {
     if (scope == SC_WAVE) {
       switch (nv) {
         case 2: hipLaunchKernelGGL((k_quant_wave<FMT, 2, SEL>), grid, dim3(256), lds, st, p); break;
@@ -1262,6 +1277,7 @@ void MQ_CAT(mq_launch_fmt, MQ_PART)(int sel_mode, int scope, int nv, int threads
                                     hipStream_t st, const QuantBatch& b) {
   if (sel_mode == SEL_FEED_SAMPLE) launch_fmt<MQ_PART_FMT, SEL_FEED_SAMPLE>(scope, nv, threads, team_log2, grid, lds, st, b);
   else if (sel_mode == SEL_FEED_COUNT) launch_fmt<MQ_PART_FMT, SEL_FEED_COUNT>(scope, nv, threads, team_log2, grid, lds, st, b);
+  else if (sel_mode == SEL_STATS_ONLY) launch_fmt<MQ_PART_FMT, SEL_STATS_ONLY>(scope, nv, threads, team_log2, grid, lds, st, b);
   else launch_fmt<MQ_PART_FMT, SEL_FEED_OFF>(scope, nv, threads, team_log2, grid, lds, st, b);
 }
 #endif
@@ -1455,11 +1471,13 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     prof_events.push_back(e1);
     MQ_HIP(hipEventRecord(e0, st));
   }
+  // statistics only: the kernels compiled without the output stores
+  const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
   switch (fmt) {
-    case MQ_INT_SYM: mq_launch_fmt1(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
-    case MQ_INT_ASYM: mq_launch_fmt2(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
-    case MQ_LUT_FP: mq_launch_fmt3(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
-    default: mq_launch_fmt4(sel_mode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    case MQ_INT_SYM: mq_launch_fmt1(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    case MQ_INT_ASYM: mq_launch_fmt2(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    case MQ_LUT_FP: mq_launch_fmt3(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
+    default: mq_launch_fmt4(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
   }
   MQ_HIP(hipGetLastError());
   if (timed) MQ_HIP(hipEventRecord(prof_events.back(), st));
