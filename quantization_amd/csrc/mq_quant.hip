@@ -702,16 +702,17 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
   const bool lane_in_seg = tl < p.vecs_per_seg;
   // Software pipeline: the next tile's loads are issued before the current tile is computed, so a wave
   // keeps 2 x NV KiB in flight.
-  u32x4 nxt[NV];
+  // (the sampling pass holds only its one slot: NJ = 1, slot index js)
+  constexpr int NJ = samp ? 1 : NV;
+  u32x4 nxt[NJ];
   auto issue = [&](int64_t t, u32x4* dst) {
     const int64_t tile = tile_of(t);
     const int js = samp ? slot_of(t) : 0;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      int64_t sg = (tile * NV + j) * SPW + team;
-      dst[j] = (lane_in_seg && sg < p.nseg && (!samp || j == js))
-                   ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
-                   : u32x4{0, 0, 0, 0};
+    for (int j = 0; j < NJ; ++j) {
+      int64_t sg = (tile * NV + (samp ? js : j)) * SPW + team;
+      dst[j] = (lane_in_seg && sg < p.nseg) ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)tl * 8)
+                                            : u32x4{0, 0, 0, 0};
     }
   };
   if (gw < steps) issue(gw, nxt);
@@ -720,18 +721,18 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
     const int js = samp ? slot_of(t) : 0;
     // dense sample index of an element = its offset inside the sampled slot + t * (slot size)
     if constexpr (samp) acc.sel.sample_shift = (t - (tile * NV + js)) * (int64_t)SPW * p.L;
-    u32x4 raw[NV];
-    bool valid[NV];
-    int64_t seg[NV];
+    u32x4 raw[NJ];
+    bool valid[NJ];
+    int64_t seg[NJ];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       raw[j] = raw_to_f16(nxt[j], p.in_dtype);
-      seg[j] = (tile * NV + j) * SPW + team;
-      valid[j] = lane_in_seg && seg[j] < p.nseg && (!samp || j == js);
+      seg[j] = (tile * NV + (samp ? js : j)) * SPW + team;
+      valid[j] = lane_in_seg && seg[j] < p.nseg;
     }
     if (t + nwaves < steps) issue(t + nwaves, nxt);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       SegP sp;
       if constexpr (FMT == MQ_INT_ASYM) {
         uint32_t lo, hi;
@@ -1439,6 +1440,11 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   int64_t max_grid = scope == SC_BLOCK || scope == -1 ? (threads == 1024 ? MQ_MAX_GRID / 4 : MQ_MAX_GRID) : grid_cap();
   // a batch shares the chip: keep the total number of workgroups near the single-tensor cap
   if (count > 1 && max_grid > 64) max_grid = max_grid / count < 64 ? 64 : max_grid / count;
+  if (sel_mode == SEL_FEED_SAMPLE && scope == SC_SUBWAVE) {
+    // one slot of every 8 tiles: few enough waves to be resident at once, 4 prefetched steps each
+    work_blocks = (work_blocks * 4 / 8 + 15) / 16;
+    if (work_blocks < 1) work_blocks = 1;
+  }
   dim3 grid((unsigned)(work_blocks < max_grid ? work_blocks : max_grid), (unsigned)count);
 
   if (sampled) {
