@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .error_metrics import error_stats, percentile, percentile_multi, true_div
-from .fused import LUT_FORMATS, quantize, quantize_batch
+from .fused import LUT_FORMATS, TABLE_LISTS, quantize, quantize_batch, quantize_table
 
 MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
 SINGLE_COLUMNS = ["datatype", "granularity", "bits", "num_channels", "groups_per_channel", "mse_tensor", "mse_rep",
@@ -23,8 +23,8 @@ def format_code(datatype: str) -> Tuple[int, Optional[str]]:
     substrings (quant_weight.py:653-706)."""
     if datatype.startswith("int"):
         return (_lib.INT_ASYM if "asym" in datatype else _lib.INT_SYM), None
-    if datatype in LUT_FORMATS:
-        return _lib.LUT_FP, datatype
+    if datatype in LUT_FORMATS or (datatype in TABLE_LISTS and datatype != "fp8_e5m2"):
+        return _lib.LUT_FP, datatype   # explicit-list tables go through mq_quantize_table (layer_record)
     raise ValueError(f"Unsupported datatype {datatype}")
 
 
@@ -60,10 +60,15 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
     K, C = w.shape
     L = C if granularity(group_size) == "per-channel" else group_size
     scratch = scratch if scratch is not None else {}
-    res = quantize(w, fmt, bits, group_size, table, deq=(form == "multi"), codes=False, scale=False,
-                   abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"), totals=True,
-                   out=scratch.get("res"))
-    scratch["res"] = res
+    if table in TABLE_LISTS:
+        res = quantize_table(w, TABLE_LISTS[table], _lib.TABLE_F16, group_size, deq=(form == "multi"), codes=False,
+                             scale=False, abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"),
+                             totals=True)
+    else:
+        res = quantize(w, fmt, bits, group_size, table, deq=(form == "multi"), codes=False, scale=False,
+                       abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"), totals=True,
+                       out=scratch.get("res"))
+        scratch["res"] = res
     rec = torch.zeros(len(RECORD_FIELDS), dtype=torch.float64, device=w.device)
     rec[0] = w.numel()
     rec[1:3] = res.totals
@@ -95,6 +100,8 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     if not weights:
         raise ValueError("model_records() needs at least one weight")
     dev = weights[0].device
+    if table in TABLE_LISTS:   # explicit-list tables: layer by layer (their kernel takes one tensor)
+        return torch.stack([layer_record(w, datatype, bits, group_size, abs_p99=abs_p99) for w in weights])
     out = torch.zeros(len(weights), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
     groups: Dict[Tuple, List[int]] = {}
     for i, w in enumerate(weights):
@@ -154,6 +161,34 @@ def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", dev
                          "mse_tensor": stats["mse_tensor"], "mse_rep": stats.get("mse_rep", ""),
                          "mse_p99": stats.get("mse_p99", "")})
     return rows
+
+
+def compare_onnx_single(baseline_model: str, quant_models: Iterable[str], initializer: str, bins: int = 50,
+                        device=None):
+    """main() of MSE&P99/quant_error_single_weight.py:85-140 for one initializer of the baseline model and several
+    quantized models: one CSV row per quantized model (tensor MSE; mean and P99 of the per-row / per-(row, group)
+    MSE list) and, in place of the script's plt.hist(vec, bins=50) calls (:118-124), each list's np.histogram
+    counts and edges computed on the device.  -> (rows, {label: (counts int64 tensor, edges ndarray)})"""
+    from .error_metrics import compute_errors, histogram
+    from .onnx_io import OnnxWeights
+    rows, hists = [], {}
+    with OnnxWeights(baseline_model) as base:
+        if initializer not in set(base.names()):
+            raise ValueError(f"{initializer} not in baseline.")   # :90-91
+        a = base.tensor(initializer, device).float()
+    for qpath in quant_models:
+        grouping, dtype, bits, gs = parse_quant_config(qpath)
+        with OnnxWeights(qpath) as quant:
+            if initializer not in set(quant.names()):
+                continue                                           # the script warns and skips (:101-103)
+            b = quant.tensor(initializer, device).float()
+        stats = compute_errors(a, b, grouping, gs, form="single", keep_per_vec=True)
+        rows.append({"datatype": dtype, "granularity": grouping, "bits": bits or "",
+                     "mse_tensor": stats["mse_tensor"], "mse_rep": stats.get("mse_rep", ""),
+                     "mse_p99": stats.get("mse_p99", "")})
+        if "per_vec" in stats:
+            hists[f"{dtype}-{grouping}"] = histogram(stats["per_vec"], bins=bins)
+    return rows, hists
 
 
 def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size) -> List[Dict]:

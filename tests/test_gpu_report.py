@@ -102,3 +102,19 @@ def test_model_records_equals_per_layer_records():
         want = torch.stack([report.layer_record(w, datatype, 8, gs, form="single") for w in sub]).cpu()
         assert torch.equal(got[:, [0, 1, 2, 4, 5]], want[:, [0, 1, 2, 4, 5]]), (datatype, gs)
         assert torch.allclose(got[:, 3], want[:, 3], rtol=1e-12, atol=0), (datatype, gs)
+
+
+def test_layer_record_explicit_list_table(oracle):
+    """Formats that go through mq_quantize_table (flint4 here) in the per-layer record and the model sweep."""
+    from quantization_amd import fused, report
+    torch.manual_seed(2)
+    w = (torch.randn(32, 256) * 0.02).half()
+    exp = oracle.quantize_table(w.numpy(), oracle.F16, fused.TABLE_LISTS["flint4"], oracle.TABLE_F16, 64)
+    st = oracle.compute_errors_single(w.numpy().astype(np.float32),
+                                      exp["deq"].view(np.float16).astype(np.float32), "per-group", 64)
+    rec = report.layer_record(w.cuda(), "flint4", 4, 64).cpu().numpy()
+    assert rec[0] == w.numel()
+    assert abs(rec[1] / rec[0] - st["mse_tensor"]) <= 1e-6 * st["mse_tensor"]
+    assert abs(rec[3] - st["mse_rep"]) <= 1e-6 * st["mse_rep"] and abs(rec[4] - st["mse_p99"]) <= 1e-6 * st["mse_p99"]
+    both = report.model_records([w.cuda(), w.cuda()], "flint4", 4, 64).cpu().numpy()
+    assert np.array_equal(both[0], rec) and np.array_equal(both[1], rec)

@@ -91,6 +91,42 @@ def test_compare_onnx_report(io, tmp_path, oracle):
     assert out.read_text().splitlines()[0] == "initializer,datatype,granularity,bits,mse_tensor,mse_rep,mse_p99"
 
 
+@pytest.mark.gpu
+def test_compare_onnx_single_weight(io, tmp_path, oracle):
+    """One initializer against several quantized models -> the rows of quant_error_single_weight.py and the counts
+    its plt.hist(vec, bins=50) calls would draw, against the numpy restatement / np.histogram."""
+    import torch
+    import quantization_amd as qa
+    from quantization_amd import report
+    root = str(tmp_path)
+    base_path, inits = _model(root, os.path.join("onnx_graph", "m", "baseline", "fp16"))
+    w = torch.from_numpy(inits["fc1.weight"]).cuda()
+    variants = {("per-channel", "fp4", "w_4_gs_none"): qa.quant_weight.quant_datatype(w, 4, "fp4", None),
+                ("per-group", "int8", "w_8_gs_16"): qa.quant_weight.quant_int(w, 8, 16),
+                ("per-group", "flint4", "w_4_gs_16"): qa.quant_weight.quant_datatype(w, 4, "flint4", 16)}
+    qpaths, deqs = [], []
+    for (grouping, dtype, leaf), deq in variants.items():
+        qp = os.path.join(root, "onnx_graph", "m", grouping, dtype, leaf, "model.onnx")
+        write_model(qp, {"fc1.weight": deq.cpu().numpy()}, [])
+        qpaths.append(qp)
+        deqs.append(deq.cpu().numpy())
+    other = os.path.join(root, "onnx_graph", "m", "per-channel", "int8", "w_8_gs_none", "model.onnx")
+    write_model(other, {"something.else": inits["small.weight"]}, [])     # lacks the initializer: skipped
+    rows, hists = report.compare_onnx_single(base_path, qpaths + [other], "fc1.weight")
+    assert [(r["granularity"], r["datatype"], r["bits"]) for r in rows] == [("per-channel", "fp4", 4),
+                                                                           ("per-group", "int8", 8),
+                                                                           ("per-group", "flint4", 4)]
+    a = inits["fc1.weight"].astype(np.float32)
+    for r, deq, gs in zip(rows, deqs, (None, 16, 16)):
+        want = oracle.compute_errors_single(a, deq.astype(np.float32), r["granularity"], gs)
+        for k in ("mse_tensor", "mse_rep", "mse_p99"):
+            assert abs(r[k] - want[k]) <= 1e-6 * abs(want[k]), (r["datatype"], k)
+        counts, edges = hists[f"{r['datatype']}-{r['granularity']}"]
+        assert counts.sum().item() == want["per_vec"].size and len(edges) == 51
+    with pytest.raises(ValueError):
+        report.compare_onnx_single(base_path, qpaths, "no.such.weight")
+
+
 def test_reader_survives_corrupt_files_under_sanitizers(tmp_path):
     """The reader parses files it did not write: build it with AddressSanitizer + UBSan (host code only) and
     feed it truncations and random byte flips of a valid model."""
