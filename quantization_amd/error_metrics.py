@@ -281,6 +281,11 @@ class QuantizationErrorAnalyzer:
     def get_sliced_abs_error_sum(self) -> float:
         return float(self._sliced["totals"][1].item()) if self._sliced else 0.0
 
+    def abs_error_histogram(self, bins: int = 200, range=None):
+        """What _plot_histogram's plt.hist(abs_err, bins=200) draws (:208-215, :273-277): np.histogram counts and
+        edges of the absolute error, counted on the device."""
+        return histogram(self.abs_elementwise_error, bins=bins, range=range)
+
 
 @torch.no_grad()
 def bucketize(w_fp16: torch.Tensor, w_q: torch.Tensor, step: float = 0.0001, max_value: float = 0.0007):

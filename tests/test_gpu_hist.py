@@ -72,3 +72,14 @@ def test_weight_histogram_two_pass(em):
     assert np.array_equal(got.cpu().numpy(), want) and want.sum() == sum(a.size for a in arrs)
     mm = em.minmax(ws[0].cuda())
     assert mm.tolist() == [float(arrs[0].min()), float(arrs[0].max())]
+
+
+def test_analyzer_abs_error_histogram(em):
+    torch.manual_seed(1)
+    w = (torch.randn(300, 257) * 0.02).half()
+    q = (w.float() + torch.randn(300, 257) * 2e-4).half()
+    an = em.QuantizationErrorAnalyzer(w.cuda(), q.cuda())
+    counts, edges = an.abs_error_histogram(200)
+    a = np.abs(w.numpy().astype(np.float32) - q.numpy().astype(np.float32)).ravel()
+    want, want_edges = np.histogram(a, bins=200)
+    assert np.array_equal(edges, want_edges) and np.array_equal(counts.cpu().numpy(), want)
