@@ -391,3 +391,39 @@ def test_quant_model_batched_equals_per_layer(qa):
                 assert torch.equal(m.weight_zp.view(torch.int16), zp.view(torch.int16)), (datatype, i, "zp")
             else:
                 assert not hasattr(m, "weight_zp")
+
+
+@pytest.mark.parametrize("fmt", ["int8", "int8_asym", "fp8_e4m3", "fp4"])
+def test_statistics_only_mode_equals_general_mode(qa, fmt):
+    """Without any element-sized output the kernels compiled without the stores run (the model sweeps): scales,
+    zero-points, per-segment and per-tensor sums must have the bits the general kernels produce."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize, quantize_batch
+    code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
+    table = fmt if code == _lib.LUT_FP else None
+    bits = 4 if fmt == "fp4" else 8
+    torch.manual_seed(9)
+    for (rows, cols, gs, dt) in [(64, 1024, 32, torch.float16), (48, 1024, 64, torch.bfloat16), (40, 2048, 128, torch.float16),
+                                 (33, 2048, None, torch.float16), (9, 5632, None, torch.bfloat16), (5, 28672, None, torch.float16),
+                                 (3, 70000, None, torch.float32), (16, 512, 512, torch.float16), (7, 96, 24, torch.float16),
+                                 (4, 4096, -1, torch.float16)]:
+        w = (torch.randn(rows, cols) * 0.02).to(dt).cuda()
+        w[0, 3] = 0.5
+        if rows > 2:
+            w[2] = 0
+        full = quantize(w, code, bits, gs, table, deq=True, codes=True, scale=True, seg_sse=True, totals=True)
+        stats = quantize(w, code, bits, gs, table, deq=False, codes=False, scale=True, seg_sse=True, totals=True)
+        what = (fmt, rows, cols, gs, dt)
+        assert torch.equal(full.scale.view(torch.int16), stats.scale.view(torch.int16)), what
+        if code == _lib.INT_ASYM:
+            assert torch.equal(full.zero_point.view(torch.int16), stats.zero_point.view(torch.int16)), what
+        assert torch.equal(full.seg_sse, stats.seg_sse), what
+        assert torch.equal(full.totals, stats.totals), what
+        # and the error sums belong to the dequantized values the general kernel returned
+        err = (w.to(torch.float16).float() - full.deq.float())
+        want = (err * err).double().sum().item()
+        assert abs(stats.totals[0].item() - want) <= 1e-6 * want, what
+    w3 = (torch.randn(5, 256, 1024) * 0.02).half().cuda()
+    b_full = quantize_batch(w3, code, bits, 128, table, deq=True, codes=False, scale=True, seg_sse=True, totals=True)
+    b_stats = quantize_batch(w3, code, bits, 128, table, deq=False, codes=False, scale=False, seg_sse=True, totals=True)
+    assert torch.equal(b_full.seg_sse, b_stats.seg_sse) and torch.equal(b_full.totals, b_stats.totals)
