@@ -762,6 +762,77 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// SC_SUBWAVE, statistics only, L = 32 * T (T = 1 .. 16 lanes): the 4 vectors a lane holds belong to ONE segment
+// (vector j * T + tl of it), so the reduction, the segment's parameters and the per-segment sum are paid once per
+// 4 vectors instead of once per vector -- the group sweeps are bound by instruction issue, not by memory.  A load
+// instruction reads runs of 16 * T bytes; the other three cover the gaps right after it.  (Not used when
+// element-sized outputs are stored: their stores would be split the same way.)
+// ------------------------------------------------------------------------------------------------
+template <int FMT, int T>
+__global__ __launch_bounds__(256) void k_quant_team4(const QuantBatch b) {
+  constexpr int NV = 4, SEL = SEL_STATS_ONLY;
+  const QuantParams p = batch_params(b);
+  __shared__ double lds[32];
+  double acc_sse = 0.0;
+  Acc acc;
+  acc.abs = 0.0;
+  acc.xp = nullptr;
+  const int lane = threadIdx.x & 63;
+  const int tl = lane & (T - 1), team = lane / T;
+  constexpr int SPW = 64 / T;  // segments per wave and step
+  const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int64_t steps = (p.nseg + SPW - 1) / SPW;
+  u32x4 nxt[NV];
+  auto issue = [&](int64_t t, u32x4* dst) {
+    const int64_t sg = t * SPW + team;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      dst[j] = sg < p.nseg ? load8_raw(p.w, p.in_dtype, sg * p.L + (int64_t)(j * T + tl) * 8) : u32x4{0, 0, 0, 0};
+  };
+  if (gw < steps) issue(gw, nxt);
+  for (int64_t t = gw; t < steps; t += nwaves) {
+    const int64_t seg = t * SPW + team;
+    const bool valid = seg < p.nseg;
+    u32x4 raw[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) raw[j] = raw_to_f16(nxt[j], p.in_dtype);
+    if (t + nwaves < steps) issue(t + nwaves, nxt);
+    SegP sp;
+    if constexpr (FMT == MQ_INT_ASYM) {
+      uint32_t mm = 0xfc007c00u;  // (+inf, -inf): neutral
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        uint32_t lo, hi;
+        minmax8_pk(raw[j], lo, hi);
+        if (valid) mm = op_minmax(mm, fold_minmax(lo, hi));
+      }
+      sp = params_minmax(team_reduce_u32<T>(mm, op_minmax), p);
+    } else {
+      uint32_t m2 = 0;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) m2 = pk_max_u16(m2, absmax8_pk(raw[j]));
+      sp = params_absmax(team_reduce_u32<T>(fold_max_u16(m2), op_max_u32), p);
+    }
+    double s = 0.0;
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) s += quant8<FMT, SEL>(p, raw[j], sp, seg * p.L + (int64_t)(j * T + tl) * 8, acc);
+    }
+    acc_sse += s;
+    if (p.seg_sse) {
+      s = team_sum<T>(s);
+      if (valid && tl == 0) p.seg_sse[seg] = s;
+    }
+    if (valid && tl == 0) {
+      if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+    }
+  }
+  block_partials(p, acc_sse, acc.abs, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
 // SC_WAVE / SC_BLOCK: a segment (a row, or a long group) is held in the registers of one wave or one
 // workgroup, NV vectors per lane, interleaved so that every load instruction is 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------------
@@ -1240,6 +1311,18 @@ template <int FMT, int SEL>
 static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
                        const QuantBatch& p) {
   if (scope == SC_SUBWAVE) {
+    if constexpr (SEL == SEL_STATS_ONLY) {
+      if (nv == -4) {  // L = 32 * 2^team_log2: four vectors of one segment per lane
+        switch (team_log2) {
+          case 0: hipLaunchKernelGGL((k_quant_team4<FMT, 1>), grid, dim3(256), 0, st, p); break;
+          case 1: hipLaunchKernelGGL((k_quant_team4<FMT, 2>), grid, dim3(256), 0, st, p); break;
+          case 2: hipLaunchKernelGGL((k_quant_team4<FMT, 4>), grid, dim3(256), 0, st, p); break;
+          case 3: hipLaunchKernelGGL((k_quant_team4<FMT, 8>), grid, dim3(256), 0, st, p); break;
+          default: hipLaunchKernelGGL((k_quant_team4<FMT, 16>), grid, dim3(256), 0, st, p); break;
+        }
+        return;
+      }
+    }
     launch_team<FMT, 4, SEL>(team_log2, grid, lds, st, p);
     return;
   }
@@ -1479,6 +1562,14 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   }
   // statistics only: the kernels compiled without the output stores
   const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
+  if (kmode == SEL_STATS_ONLY && scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0 && !sampled) {
+    // groups of 32 * 2^k elements: the kernel that holds four vectors of one segment per lane
+    team_log2 = ilog2_ceil(p.L / 32);
+    nv = -4;
+    const int64_t spw = 64 >> team_log2;
+    const int64_t wb = ((p.nseg + spw - 1) / spw + 3) / 4;
+    grid.x = (unsigned)(wb < max_grid ? wb : max_grid);
+  }
   switch (fmt) {
     case MQ_INT_SYM: mq_launch_fmt1(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
     case MQ_INT_ASYM: mq_launch_fmt2(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;

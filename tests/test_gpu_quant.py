@@ -395,8 +395,9 @@ def test_quant_model_batched_equals_per_layer(qa):
 
 @pytest.mark.parametrize("fmt", ["int8", "int8_asym", "fp8_e4m3", "fp4"])
 def test_statistics_only_mode_equals_general_mode(qa, fmt):
-    """Without any element-sized output the kernels compiled without the stores run (the model sweeps): scales,
-    zero-points, per-segment and per-tensor sums must have the bits the general kernels produce."""
+    """Without any element-sized output the kernels compiled without the stores run (the model sweeps): scales
+    and zero-points must have the bits the general kernels produce, per-segment and per-tensor sums the same value
+    up to the order of the float64 additions."""
     from quantization_amd import _lib
     from quantization_amd.fused import quantize, quantize_batch
     code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
@@ -405,7 +406,7 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
     torch.manual_seed(9)
     for (rows, cols, gs, dt) in [(64, 1024, 32, torch.float16), (48, 1024, 64, torch.bfloat16), (40, 2048, 128, torch.float16),
                                  (33, 2048, None, torch.float16), (9, 5632, None, torch.bfloat16), (5, 28672, None, torch.float16),
-                                 (3, 70000, None, torch.float32), (16, 512, 512, torch.float16), (7, 96, 24, torch.float16),
+                                 (3, 70000, None, torch.float32), (16, 512, 512, torch.float16), (7, 96, 24, torch.float16), (11, 768, 256, torch.bfloat16),
                                  (4, 4096, -1, torch.float16)]:
         w = (torch.randn(rows, cols) * 0.02).to(dt).cuda()
         w[0, 3] = 0.5
@@ -417,8 +418,9 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
         assert torch.equal(full.scale.view(torch.int16), stats.scale.view(torch.int16)), what
         if code == _lib.INT_ASYM:
             assert torch.equal(full.zero_point.view(torch.int16), stats.zero_point.view(torch.int16)), what
-        assert torch.equal(full.seg_sse, stats.seg_sse), what
-        assert torch.equal(full.totals, stats.totals), what
+        # (same float32 squares; the group kernel of this mode adds them in another float64 order)
+        torch.testing.assert_close(stats.seg_sse, full.seg_sse, rtol=1e-13, atol=0)
+        torch.testing.assert_close(stats.totals, full.totals, rtol=1e-13, atol=0)
         # and the error sums belong to the dequantized values the general kernel returned
         err = (w.to(torch.float16).float() - full.deq.float())
         want = (err * err).double().sum().item()
@@ -426,4 +428,5 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
     w3 = (torch.randn(5, 256, 1024) * 0.02).half().cuda()
     b_full = quantize_batch(w3, code, bits, 128, table, deq=True, codes=False, scale=True, seg_sse=True, totals=True)
     b_stats = quantize_batch(w3, code, bits, 128, table, deq=False, codes=False, scale=False, seg_sse=True, totals=True)
-    assert torch.equal(b_full.seg_sse, b_stats.seg_sse) and torch.equal(b_full.totals, b_stats.totals)
+    torch.testing.assert_close(b_stats.seg_sse, b_full.seg_sse, rtol=1e-13, atol=0)
+    torch.testing.assert_close(b_stats.totals, b_full.totals, rtol=1e-13, atol=0)
