@@ -1,0 +1,82 @@
+"""GPU: the headline workload at its full size -- batches of 4096 x 4096 matrices, where the launches are
+grid-capped and every workgroup loops over many tiles -- against the CPU oracle (one matrix of each batch, bit for
+bit), against numpy's percentile of the dumped errors, and through size-independent properties of the outputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("fmt,gs", [("int8_asym", 32), ("int8_asym", 128), ("int8", 64), ("fp8_e4m3", 128),
+                                    ("int8", None), ("fp8_e3m4", None)])
+def test_c2_sized_batch(oracle, fmt, gs):
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize_batch
+    code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
+    ocode = {"int8": oracle.INT_SYM, "int8_asym": oracle.INT_ASYM}.get(fmt, oracle.LUT)
+    table = fmt if code == _lib.LUT_FP else None
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 6
+    w = (torch.randn(B, 4096, 4096, generator=g, device="cuda") * 0.02).half()
+    res = quantize_batch(w, code, 8, gs, table, deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True,
+                         totals=True, p99=99)
+    # 1) one matrix of the batch against the oracle, bit for bit
+    i = B - 1
+    exp = oracle.quantize(w[i].cpu().numpy(), oracle.F16, ocode, 8, gs, datatype=table, nthreads=16)
+    assert np.array_equal(bits16(res.deq[i]), exp["deq"])
+    got_q = bits16(res.codes[i]) if code == _lib.LUT_FP else res.codes[i].cpu().numpy()
+    assert np.array_equal(got_q, exp["q"])
+    assert np.array_equal(bits16(res.scale[i]), exp["scale"])
+    if code == _lib.INT_ASYM:
+        assert np.array_equal(bits16(res.zero_point[i]), exp["zp"])
+    # 2) every matrix: the dump is |float32(w) - float32(deq)| exactly; sums and P99 belong to it
+    err = (w.float() - res.deq.float()).abs()
+    assert torch.equal(res.abs_err, err)
+    sq = (err * err).double()
+    # (a lane's 8 squares / absolute values are added in float32 before the float64 sums: 3 roundings, 1.8e-7)
+    torch.testing.assert_close(res.totals[:, 0], sq.sum(dim=(1, 2)), rtol=2e-7, atol=0)
+    torch.testing.assert_close(res.totals[:, 1], err.double().sum(dim=(1, 2)), rtol=2e-7, atol=0)
+    L = gs if gs else 4096
+    torch.testing.assert_close(res.seg_sse, sq.reshape(B, -1, L).sum(dim=2), rtol=2e-7, atol=0)
+    for k in (0, i):
+        want = np.percentile(err[k].cpu().numpy().ravel(), 99)
+        assert res.abs_p99[k].cpu().numpy().view(np.uint32) == want.view(np.uint32)
+    # 3) properties: codes reproduce the dequantized values from scale / zero-point (float16 op by op), and for the
+    #    symmetric format no error exceeds 0.6 steps of its segment (half a step, plus the float16 roundings of
+    #    v / s at |v / s| <= 127 and of q * s; the asymmetric format may clip at the ends of its range)
+    s = res.scale.reshape(B, -1, 1)
+    if code == _lib.LUT_FP:
+        back = (res.codes.reshape(B, -1, L) * s).reshape(B, 4096, 4096)
+    elif code == _lib.INT_ASYM:
+        z = res.zero_point.reshape(B, -1, 1)
+        back = ((res.codes.reshape(B, -1, L).half() - z) * s).reshape(B, 4096, 4096)
+    else:
+        back = (res.codes.view(torch.int8).reshape(B, -1, L).half() * s).reshape(B, 4096, 4096)
+    assert torch.equal(back, res.deq)   # as values: a symmetric zero code dequantizes to -0 for negative weights
+    if code == _lib.INT_SYM:
+        bound = (s.float() * 0.6).expand(B, s.shape[1], L).reshape(B, 4096, 4096)
+        assert bool((err <= bound).all())
+
+
+def test_llama_sized_rows_vs_oracle(oracle):
+    """Row lengths of the Llama shape lists (workgroup-per-row kernels, 256 and 1024 threads), bf16 input."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    torch.manual_seed(6)
+    for cols in (5632, 14336, 28672):
+        w = (torch.randn(24, cols) * 0.02).bfloat16()
+        wb = w.view(torch.int16).numpy().view(np.uint16)
+        for code, ocode, table in ((_lib.INT_SYM, oracle.INT_SYM, None), (_lib.INT_ASYM, oracle.INT_ASYM, None),
+                                   (_lib.LUT_FP, oracle.LUT, "fp8_e4m3"), (_lib.LUT_FP, oracle.LUT, "fp4")):
+            bits = 4 if table == "fp4" else 8
+            exp = oracle.quantize(wb, oracle.BF16, ocode, bits, None, datatype=table)
+            res = quantize(w.cuda(), code, bits, None, table, seg_sse=True, totals=True)
+            assert np.array_equal(bits16(res.deq), exp["deq"]), (cols, table, code)
+            assert np.array_equal(bits16(res.scale), exp["scale"]), (cols, table, code)
+            e = exp["v16"].view(np.float16).astype(np.float32) - exp["deq"].view(np.float16).astype(np.float32)
+            np.testing.assert_allclose(res.seg_sse.cpu().numpy(), (e * e).astype(np.float64).sum(1), rtol=2e-7)
