@@ -230,6 +230,91 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
   }
 }
 
+// ---- short arrays: the whole selection in one launch ------------------------------------------------------
+// One 1024-thread workgroup per array of up to SEL_SMALL_N values (per-channel MSE lists: a few thousand values per
+// tensor, for which the chain of clear / histogram / scan launches above is pure launch latency).  The keys are
+// resolved 11 bits at a time -- 3 sweeps for float32, 6 for float64, the array stays in L2 -- with one LDS
+// histogram per tracked rank, then interpolated as k_sel_scan does.
+#define SEL_SMALL_N 32768
+#define SEL_SMALL_BITS 11
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+  constexpr int NB = 1 << SEL_SMALL_BITS;
+  __shared__ uint32_t hist[2][NB];
+  __shared__ uint32_t wtot[16];
+  __shared__ uint64_t s_prefix[2], s_rank[2];
+  const T* x = static_cast<const T*>(b.x[blockIdx.x]);
+  const int64_t n = b.n[blockIdx.x];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_prefix[0] = s_prefix[1] = 0;
+    s_rank[0] = rk.k0[blockIdx.x];
+    s_rank[1] = rk.k1[blockIdx.x];
+  }
+  int remaining = sizeof(T) == 4 ? 31 : 63;  // key bits still unresolved; float32 keys sit in the high word
+  const int low = sizeof(T) == 4 ? 32 : 0;    // bits below the key
+  while (remaining > 0) {
+    const int width = remaining < SEL_SMALL_BITS ? remaining : SEL_SMALL_BITS;
+    const int shift = low + remaining - width;
+    for (int i = threadIdx.x; i < 2 * NB; i += blockDim.x) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint64_t p0 = s_prefix[0], p1 = s_prefix[1];
+    const bool same = p0 == p1;
+    const uint64_t himask = remaining == (sizeof(T) == 4 ? 31 : 63) ? 0ull : ~((1ull << (shift + width)) - 1ull);
+    const uint32_t dmask = (1u << width) - 1u;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t key = key_of(x[i]);
+      const uint32_t d = (uint32_t)(key >> shift) & dmask;
+      if ((key & himask) == p0) atomicAdd(&hist[0][d], 1u);
+      if (!same && (key & himask) == p1) atomicAdd(&hist[1][d], 1u);
+    }
+    __syncthreads();
+    // locate each rank: every thread owns two consecutive bins
+    for (int r = 0; r < 2; ++r) {
+      const uint32_t* h = hist[(same || r == 0) ? 0 : 1];
+      const uint64_t want = s_rank[r];
+      const uint32_t c0 = h[2 * threadIdx.x], c1 = h[2 * threadIdx.x + 1];
+      uint32_t inc = c0 + c1;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      __syncthreads();  // (s_rank / wtot of the previous round have been read)
+      if (lane == 63) wtot[wv] = inc;
+      __syncthreads();
+      uint64_t before = inc - (c0 + c1);
+      for (int w = 0; w < wv; ++w) before += wtot[w];
+      if (want >= before && want < before + c0) {
+        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint64_t)(2 * threadIdx.x) << shift);
+        s_rank[r] = want - before;
+      } else if (want >= before + c0 && want < before + c0 + c1) {
+        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint64_t)(2 * threadIdx.x + 1) << shift);
+        s_rank[r] = want - before - c0;
+      }
+      __syncthreads();
+    }
+    remaining -= width;
+  }
+  if (threadIdx.x == 0) {
+    if (fin.dtype == MQ_F32) {
+      float a = f_from_bits((uint32_t)(s_prefix[0] >> 32)), c = f_from_bits((uint32_t)(s_prefix[1] >> 32));
+      float g = (float)rk.gamma[blockIdx.x], diff = c - a;
+      float v = a + diff * g;
+      if (g >= 0.5f) v = c - diff * (1.0f - g);
+      if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
+      if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+    } else {
+      double a = __builtin_bit_cast(double, s_prefix[0]), c = __builtin_bit_cast(double, s_prefix[1]);
+      double g = rk.gamma[blockIdx.x], diff = c - a;
+      double v = a + diff * g;
+      if (g >= 0.5) v = c - diff * (1.0 - g);
+      if (fin.out) reinterpret_cast<double*>(fin.out)[blockIdx.x] = v;
+      if (fin.out_pair) { reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+    }
+  }
+}
+
 // ---- levels 1..3 -----------------------------------------------------------------------------------
 // Elements whose bits above the digit equal a tracked prefix are counted per digit value; a workgroup
 // first aggregates them in an LDS hash table (linear probing), then merges the table into the global
@@ -772,6 +857,27 @@ static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t
   return MQ_OK;
 }
 
+// Arrays of up to SEL_SMALL_N values: one launch, one workgroup per array, no workspace.
+static int select_small(const void* const* xs, const int64_t* ns, int c, int32_t dtype, double pct, char* out,
+                        char* out_pair, hipStream_t st) {
+  SelBatch b = {};
+  SelRanks rk = {};
+  for (int i = 0; i < c; ++i) {
+    b.x[i] = xs[i];
+    b.n[i] = ns[i];
+    int64_t k0, k1;
+    int rc = mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &rk.gamma[i]);
+    if (rc) return rc;
+    rk.k0[i] = (uint64_t)k0;
+    rk.k1[i] = (uint64_t)k1;
+  }
+  FinishArgs fin = {dtype, out, out_pair};
+  if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_small<float>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+  else hipLaunchKernelGGL((k_sel_small<double>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
 // np.percentile(xs[i], pct) for `count` non-negative arrays of ns[i] values (one dtype), one result per
 // array in out[i] (and out_pair[2 i], out_pair[2 i + 1]).  Arrays travel in groups of <= 64 per set of
 // launches: 5 launches for float32 (clear, histogram, scan, matched-digit histogram, scan + interpolation),
@@ -793,20 +899,23 @@ extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   const size_t esz = dtype == MQ_F32 ? 4 : 8;
   // consecutive arrays that take the same route form a group
+  // 0: exact multi-launch route, 1: sample + bracket in front of it, 2: short array, one launch
   auto route = [&](int i) {
     int64_t k0, k1, m;
     double g, lo, hi;
-    if (mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &g)) return false;
-    return dtype == MQ_F32 && bracket_ranks(ns[i], k0, k1, &m, &lo, &hi);
+    if (ns[i] <= SEL_SMALL_N) return 2;
+    if (mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &g)) return 0;
+    return dtype == MQ_F32 && bracket_ranks(ns[i], k0, k1, &m, &lo, &hi) ? 1 : 0;
   };
   int done = 0;
   while (done < count) {
-    const bool br = route(done);
+    const int rt = route(done);
     int c = 1;
-    while (done + c < count && c < SEL_MAX_BATCH && route(done + c) == br) ++c;
-    int rc = select_group(xs + done, ns + done, c, dtype, pct, br,
-                          out ? static_cast<char*>(out) + (size_t)done * esz : nullptr,
-                          out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr, workspace, st);
+    while (done + c < count && c < SEL_MAX_BATCH && route(done + c) == rt) ++c;
+    char* o = out ? static_cast<char*>(out) + (size_t)done * esz : nullptr;
+    char* op = out_pair ? static_cast<char*>(out_pair) + (size_t)done * 2 * esz : nullptr;
+    int rc = rt == 2 ? select_small(xs + done, ns + done, c, dtype, pct, o, op, st)
+                     : select_group(xs + done, ns + done, c, dtype, pct, rt == 1, o, op, workspace, st);
     if (rc) return rc;
     done += c;
   }

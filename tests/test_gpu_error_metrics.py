@@ -235,3 +235,35 @@ def test_compare_formats_vector_and_scalar_paths(em, oracle):
     r = em.compare_formats(tw, tq[:3], 0.02, out=flags)
     assert r["flags"] is flags
     assert torch.equal(flags, em.compare_formats(tw, tq[:3], 0.02)["flags"])
+
+
+def test_short_array_single_launch_route(em):
+    """Arrays of up to 32768 values are selected by one workgroup in one launch: lengths around the limit, tiny
+    arrays, ties, zeros and infinities, several quantiles, both dtypes, mixed into one percentile_multi call --
+    bit for bit against numpy."""
+    rng = np.random.default_rng(21)
+    for dt in (np.float32, np.float64):
+        arrays = []
+        for n in (1, 2, 3, 64, 1000, 2047, 32767, 32768, 32769, 70000):
+            arrays.append(np.abs(rng.standard_normal(n)).astype(dt) * dt(1e-7))
+        arrays.append(np.full(500, 0.25, dt))                                   # all equal
+        arrays.append(np.zeros(77, dt))
+        arrays.append(np.repeat(np.abs(rng.standard_normal(40)).astype(dt), 250))   # heavy ties
+        a = np.abs(rng.standard_normal(3000)).astype(dt)
+        a[:40] = np.inf                                                         # the top 1.3 % is infinite
+        arrays.append(a)
+        arrays.append((rng.random(9999) ** 8).astype(dt) * dt(1e-30))           # tiny magnitudes, wide exponent range
+        dev = [torch.from_numpy(x).cuda() for x in arrays]
+        for pct in (99, 50, 0, 100, 99.9, 12.5):
+            got = em.percentile_multi(dev, pct).cpu().numpy()
+            for i, x in enumerate(arrays):
+                with np.errstate(invalid="ignore"):
+                    want = np.percentile(x, pct)
+                if np.isnan(want):
+                    assert np.isnan(got[i]), (dt, pct, i)
+                else:
+                    assert got[i].tobytes() == np.asarray(want, dt).tobytes(), (dt.__name__, pct, i, x.size)
+        v, pair = em.percentile(dev[4], 99, return_pair=True)
+        srt = np.sort(arrays[4])
+        k = (arrays[4].size - 1) * 0.99
+        assert pair.cpu().numpy().tolist() == [srt[int(np.floor(k))], srt[int(np.ceil(k))]]
