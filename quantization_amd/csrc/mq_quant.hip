@@ -35,7 +35,10 @@
 #endif
 #define MQ_IS_LUT(F) ((F) == MQ_LUT_FP || (F) == MQ_LUT_FP_SUB)
 
-enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3 };
+enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3,
+       // the statistics-only kernels (k_stats_*): groups of 32 * 2^team_log2 elements; rows held by one wave / by
+       // a 256-thread workgroup with nv vectors per lane
+       SC_STATS_GROUP = 4, SC_STATS_ROW = 5, SC_STATS_ROWBLK = 6 };
 // The kernels' SEL template parameter: one of the SEL_FEED_* values, or SEL_STATS_ONLY = no selection feed and no
 // element-sized output (deq / codes / abs_err all absent: the sweeps that only want the error statistics), which
 // drops the per-vector tests of the output pointers and everything that only served the stores.
@@ -490,6 +493,82 @@ __device__ __forceinline__ void error_sums(const float* e, double& sse, double& 
   sabs += (double)a;
 }
 
+// ---- statistics-only fast path ---------------------------------------------------------------------------------
+// Measured issue cost on gfx950 (cycles per wave instruction per SIMD, 4 .. 8 waves per SIMD): plain float32
+// add / mul / fma and 32-bit and: ~2.4; every packed, conversion, mixed-precision, dot, v_bfi / v_perm, DPP and
+// float64 instruction: ~4.2; v_rcp_f32, v_med3_f16, v_max3_f16: ~8.  The sweeps that only want error statistics
+// are bound by that issue rate, so this path is written for the fewest issue cycles per pair of elements:
+//  * the float16 operands of the exact division go into v_fma_mix_f32 as they are (no float16 -> float32
+//    conversions): q0 = v * r, rem = fma(-q0, s, v), q1 = fma(rem, r, q0), the same three roundings as div_f;
+//  * e = v - d is taken in packed float16.  It is EXACT there: on this path d is 0 or within a factor 2 of v
+//    (Sterbenz), checked for every (scale, value) pair the fast path admits by tests/tools/sterbenz_exhaustive.c;
+//  * sum e^2 and sum |e| go through v_dot2_f32_f16 (float16 products are exact in float32; float16 subnormals are
+//    honoured; the two-term sum is not single-rounded, about one float32 ulp per step, far inside the 1e-6 bar).
+__device__ __forceinline__ float mix_mul_lo(uint32_t vw, float r) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(vw), "v"(r));
+  return d;
+}
+__device__ __forceinline__ float mix_mul_hi(uint32_t vw, float r) {
+  float d;
+  asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(vw), "v"(r));
+  return d;
+}
+// fma(-q0, s, v) with v the low / high float16 half of vw
+__device__ __forceinline__ float mix_rem_lo(float q0, float s, uint32_t vw) {
+  float d;
+  asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(q0), "v"(s), "v"(vw));
+  return d;
+}
+__device__ __forceinline__ float mix_rem_hi(float q0, float s, uint32_t vw) {
+  float d;
+  asm("v_fma_mix_f32 %0, -%1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(q0), "v"(s), "v"(vw));
+  return d;
+}
+// h(v / s) for both halves of vw (finite v; the sign of a zero quotient is not kept, see div_f)
+__device__ __forceinline__ h16x2 div_pk(uint32_t vw, const SegP& sp) {
+  const float q0a = mix_mul_lo(vw, sp.r), q0b = mix_mul_hi(vw, sp.r);
+  const float ra = mix_rem_lo(q0a, sp.sf, vw), rb = mix_rem_hi(q0b, sp.sf, vw);
+  const h16x2 x = {(half_t)__builtin_fmaf(ra, sp.r, q0a), (half_t)__builtin_fmaf(rb, sp.r, q0b)};
+  return x;
+}
+// sse += e.lo^2 + e.hi^2;  sabs += |e.lo| + |e.hi|
+__device__ __forceinline__ void err_dot2(h16x2 e, float& sse, float& sabs) {
+  sse = __builtin_amdgcn_fdot2(e, e, sse, false);
+  sabs = __builtin_amdgcn_fdot2(as_h2(as_u32(e) & 0x7fff7fffu), as_h2(0x3c003c00u), sabs, false);
+}
+
+// One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements (the caller carries
+// everything above that in float64).
+template <int FMT>
+__device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 raw, const SegP& sp, float& sse,
+                                             float& sabs) {
+  const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
+  const h16x2 magic = as_h2(0x66006600u);  // 1536
+  sse = 0.f;
+  sabs = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t vw = raw[k];
+    const h16x2 x = div_pk(vw, sp);
+    h16x2 d;
+    if constexpr (FMT == MQ_INT_SYM) {
+      d = ((x + magic) - magic) * s2;
+    } else if constexpr (FMT == MQ_INT_ASYM) {
+      // clamp(rint(x) + zp, 0, qmax) - zp = clamp(rint(x), -zp, qmax - zp): every value is an integer below 2048,
+      // so the float16 additions are exact; the clamp is applied to 1536 + rint(x)
+      const h16x2 zp2 = as_h2(dup16(h_bits(sp.zp)));
+      const h16x2 lo = magic - zp2, hi = lo + as_h2(dup16(h_bits((half_t)p.qmax)));
+      uint32_t t = pk_min_f16(pk_max_f16(as_u32(x + magic), as_u32(lo)), as_u32(hi));
+      d = (as_h2(t) - magic) * s2;
+    } else {
+      uint32_t qw = FMT == MQ_LUT_FP_SUB ? lut_round_pk_sub(as_u32(x), p.lut) : lut_round_pk(as_u32(x), p.lut);
+      d = as_h2(qw) * s2;
+    }
+    err_dot2(as_h2(vw) - d, sse, sabs);
+  }
+}
+
 // Fast path: packed float16 arithmetic, exact for finite data with |v / s| < 512.
 //  * rint(x) for |x| < 512 is (x + 1536) - 1536 in float16 (ulp 1 in [1024, 2048), round to nearest even);
 //    the low byte of the float16 bits of 1536 + q (0x6600 + q) is q's two's-complement byte.
@@ -497,6 +576,12 @@ __device__ __forceinline__ void error_sums(const float* e, double& sse, double& 
 template <int FMT, int SEL>
 __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                               Acc& acc) {
+  if constexpr (SEL == SEL_STATS_ONLY) {
+    float sse, sabs;
+    quant8_stats<FMT>(p, raw, sp, sse, sabs);
+    acc.abs += (double)sabs;
+    return (double)sse;
+  }
   const uint32_t s2 = dup16(h_bits(sp.s)), zp2 = dup16(h_bits(sp.zp));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
   u32x4 dq, cw;
@@ -979,6 +1064,230 @@ __global__ __launch_bounds__(THREADS) void k_quant_block(const QuantBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Statistics-only kernels of the model sweeps: float16 / bfloat16 weights, 16-byte aligned, no element-sized
+// output.  Same arithmetic as the kernels above (quant8_stats, quant8_slow for segments off the fast path), with
+// everything that is not arithmetic taken out of the loop, because these passes are bound by instruction issue:
+// a wave's position is wave-uniform (scalar base address + one per-lane byte offset + immediate offsets), the
+// input type is a template parameter, and whole steps carry no per-lane predicates.
+//   k_stats_group<FMT, BF16, T>     groups of 32 * T elements (T = 1 .. 16 lanes per group, 4 vectors per lane)
+//   k_stats_row<FMT, BF16, NV, 1>   rows of up to 512 * NV elements, one wave per row
+//   k_stats_row<FMT, BF16, NV, 4>   rows of up to 2048 * NV elements, one 256-thread workgroup per row
+// ------------------------------------------------------------------------------------------------
+template <bool BF16>
+__device__ __forceinline__ u32x4 stats_cvt(u32x4 raw) {
+  if constexpr (BF16) return bf16x8_to_f16(raw);
+  else return raw;
+}
+// one lane's reduction word over NV vectors: absmax bits, or (min | max << 16)
+template <int FMT, int NV>
+__device__ __forceinline__ uint32_t stats_lane_reduce(const u32x4* raw) {
+  if constexpr (FMT == MQ_INT_ASYM) {
+    uint32_t lo = raw[0][0], hi = raw[0][0];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (j == 0 && k == 0) continue;
+        lo = pk_min_f16(lo, raw[j][k]);
+        hi = pk_max_f16(hi, raw[j][k]);
+      }
+    return fold_minmax(lo, hi);
+  } else {
+    uint32_t m2 = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m2 = pk_max_u16(m2, raw[j][k] & 0x7fff7fffu);
+    return fold_max_u16(m2);
+  }
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t stats_op(uint32_t a, uint32_t b) {
+  if constexpr (FMT == MQ_INT_ASYM) return op_minmax(a, b);
+  else return op_max_u32(a, b);
+}
+template <int FMT>
+__device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p) {
+  if constexpr (FMT == MQ_INT_ASYM) return params_minmax(red, p);
+  else return params_absmax(red, p);
+}
+// NV vectors of one segment held by this lane -> float64 sum of squared errors; acc_abs += sum |error|
+template <int FMT, int NV>
+__device__ __forceinline__ double stats_vectors(const QuantParams& p, const u32x4* raw, const SegP& sp, bool any_slow,
+                                                double& acc_abs) {
+  double s = 0.0;
+  if (__builtin_expect(any_slow, 0)) {
+    Acc acc;
+    acc.abs = 0.0;
+    acc.xp = nullptr;
+#pragma unroll 1
+    for (int j = 0; j < NV; ++j) {
+      // (a rolled loop with a run-time index would move raw[] to scratch memory: select the vector instead)
+      u32x4 v = raw[0];
+#pragma unroll
+      for (int i = 1; i < NV; ++i) v = i == j ? raw[i] : v;
+      s += sp.slow ? quant8_slow<FMT, SEL_STATS_ONLY>(p, v, sp, 0, acc) : quant8_fast<FMT, SEL_STATS_ONLY>(p, v, sp, 0, acc);
+    }
+    acc_abs += acc.abs;
+    return s;
+  }
+  float ab = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float q, a;
+    quant8_stats<FMT>(p, raw[j], sp, q, a);
+    s += (double)q;
+    // |error| sums of up to 4 vectors (16 dot steps) stay in float32
+    ab += a;
+    if ((j & 3) == 3 || j == NV - 1) { acc_abs += (double)ab; ab = 0.f; }
+  }
+  return s;
+}
+
+template <int FMT, bool BF16, int T>
+__global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
+  constexpr int NV = 4, SPW = 64 / T;  // segments per wave and step: 4 KiB of weights
+  const QuantParams p = batch_params(b);
+  __shared__ double lds[32];
+  const int lane = threadIdx.x & 63, tl = lane & (T - 1), team = lane / T;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  const int64_t full = p.nseg / SPW, steps = (p.nseg + SPW - 1) / SPW;
+  const char* wb = static_cast<const char*>(p.w);
+  const uint32_t loff = (uint32_t)(team * (64 * T) + tl * 16);  // this lane's bytes inside the step's 4 KiB
+  double acc_sse = 0.0, acc_abs = 0.0;
+  u32x4 nxt[NV];
+  auto issue = [&](int64_t t) {
+    const char* sb = wb + t * 4096 + loff;
+    if (t < full) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) nxt[j] = *reinterpret_cast<const u32x4*>(sb + j * (16 * T));
+    } else {  // the last, partial step
+      const bool in = t * SPW + team < p.nseg;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) nxt[j] = in ? *reinterpret_cast<const u32x4*>(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
+    }
+  };
+  if (gw < steps) issue(gw);
+  for (int64_t t = gw; t < steps; t += nwaves) {
+    u32x4 raw[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(nxt[j]);
+    if (t + nwaves < steps) issue(t + nwaves);
+    const int64_t seg = t * SPW + team;
+    const bool valid = t < full || seg < p.nseg;
+    const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
+    const bool any_slow = __builtin_amdgcn_ballot_w64(sp.slow) != 0;
+    double s = stats_vectors<FMT, NV>(p, raw, sp, any_slow, acc_abs);  // (an invalid lane holds zeros: no error)
+    acc_sse += s;
+    if (p.seg_sse) {
+      s = team_sum<T>(s);
+      if (valid && tl == 0) p.seg_sse[seg] = s;
+    }
+    if (valid && tl == 0) {
+      if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+    }
+  }
+  block_partials(p, acc_sse, acc_abs, lds);
+}
+
+// Rows.  WPR waves share a row (1: a wave per row, 4: the workgroup per row); lane l of wave w holds vectors
+// (j * WPR + w) * 64 + l, j < NV, so every load instruction of a wave reads 1 KiB of consecutive bytes.  Vectors
+// past the end of a row (rows that are not a multiple of 512 * NV * WPR elements) are loaded as zeros: they
+// change neither the absolute maximum nor the error sums (min / max skip them explicitly).
+template <int FMT, bool BF16, int NV, int WPR>
+__global__ __launch_bounds__(256) void k_stats_row(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
+  __shared__ double lds[32];
+  __shared__ uint32_t xr[2][4];
+  __shared__ double xs[2][4];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t first = WPR == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x;
+  const int64_t stride = WPR == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
+  const int sub = WPR == 1 ? 0 : wv;  // which part of the row this wave holds
+  const char* wb = static_cast<const char*>(p.w);
+  const int64_t row_bytes = p.L * 2;
+  const uint32_t loff = (uint32_t)(sub * 1024 + lane * 16);
+  const bool whole = p.vecs_per_seg == 64 * NV * WPR;  // no vector of the grid lies past the row's end
+  constexpr bool PREFETCH = NV <= 8;
+  double acc_sse = 0.0, acc_abs = 0.0;
+  u32x4 nxt[PREFETCH ? NV : 1];
+  auto issue = [&](int64_t row, u32x4* dst) {
+    const char* sb = wb + row * row_bytes + loff;
+    if (whole) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) dst[j] = *reinterpret_cast<const u32x4*>(sb + j * (1024 * WPR));
+    } else {
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? *reinterpret_cast<const u32x4*>(sb + j * (1024 * WPR))
+                                                              : u32x4{0, 0, 0, 0};
+    }
+  };
+  if constexpr (PREFETCH) {
+    if (first < p.nseg) issue(first, nxt);
+  }
+  int parity = 0;
+  for (int64_t row = first; row < p.nseg; row += stride) {
+    u32x4 raw[NV];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(nxt[j]);
+      if (row + stride < p.nseg) issue(row + stride, nxt);
+    } else {
+      issue(row, raw);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
+    }
+    uint32_t red = stats_lane_reduce<FMT, NV>(raw);
+    if constexpr (FMT == MQ_INT_ASYM) {
+      if (!whole) {  // the zeros past the row's end must not enter min / max
+        red = 0xfc007c00u;  // (+inf, -inf): neutral
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          uint32_t lo, hi;
+          minmax8_pk(raw[j], lo, hi);
+          if ((j * WPR + sub) * 64 + lane < p.vecs_per_seg) red = op_minmax(red, fold_minmax(lo, hi));
+        }
+      }
+    }
+    red = team_reduce_u32<64>(red, stats_op<FMT>);
+    if constexpr (WPR > 1) {
+      if (lane == 0) xr[parity][wv] = red;
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < WPR; ++i) red = stats_op<FMT>(red, xr[parity][i]);
+    }
+    const SegP sp = stats_params<FMT>(red, p);
+    double s = stats_vectors<FMT, NV>(p, raw, sp, sp.slow, acc_abs);
+    acc_sse += s;
+    if (p.seg_sse) {
+      s = team_sum<64>(s);
+      if constexpr (WPR > 1) {
+        if (lane == 0) xs[parity][wv] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          double t = 0.0;
+#pragma unroll
+          for (int i = 0; i < WPR; ++i) t += xs[parity][i];
+          p.seg_sse[row] = t;
+        }
+      } else if (lane == 0) {
+        p.seg_sse[row] = s;
+      }
+    }
+    if (lane == 0 && sub == 0) {
+      if (p.scale) p.scale[row] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[row] = (uint16_t)h_bits(sp.zp);
+    }
+    parity ^= 1;
+  }
+  block_partials(p, acc_sse, acc_abs, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
 // SC_TENSOR: group_size == -1.  k_tensor_reduce leaves the tensor's absmax / min / max in tred[];
 // k_quant_tensor then treats the flat tensor as one segment whose parameters every lane derives itself.
 //   tred[0] max over |float16 bits|  (or |float32 bits| when f32_math)
@@ -1305,11 +1614,48 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
   }
 }
 
+template <int FMT, bool BF16>
+static void launch_stats(int scope, int nv, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
+#define MQ_STATS_ROW(NV, WPR) hipLaunchKernelGGL((k_stats_row<FMT, BF16, NV, WPR>), grid, dim3(256), 0, st, p)
+  if (scope == SC_STATS_GROUP) {
+    switch (team_log2) {
+      case 0: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 1>), grid, dim3(256), 0, st, p); break;
+      case 1: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 2>), grid, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 4>), grid, dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 8>), grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 16>), grid, dim3(256), 0, st, p); break;
+    }
+  } else if (scope == SC_STATS_ROW) {
+    switch (nv) {
+      case 2: MQ_STATS_ROW(2, 1); break;
+      case 4: MQ_STATS_ROW(4, 1); break;
+      case 8: MQ_STATS_ROW(8, 1); break;
+      case 12: MQ_STATS_ROW(12, 1); break;
+      default: MQ_STATS_ROW(16, 1); break;
+    }
+  } else {
+    switch (nv) {
+      case 7: MQ_STATS_ROW(7, 4); break;
+      case 8: MQ_STATS_ROW(8, 4); break;
+      case 14: MQ_STATS_ROW(14, 4); break;
+      default: MQ_STATS_ROW(16, 4); break;
+    }
+  }
+#undef MQ_STATS_ROW
+}
+
 // SEL: SEL_FEED_OFF / SEL_STATS_ONLY, or the two passes that feed a percentile selection (team scope only: rows
 // are not fed).
 template <int FMT, int SEL>
 static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid, size_t lds, hipStream_t st,
                        const QuantBatch& p) {
+  if constexpr (SEL == SEL_STATS_ONLY) {
+    if (scope >= SC_STATS_GROUP) {
+      if (p.common.in_dtype == MQ_BF16) launch_stats<FMT, true>(scope, nv, team_log2, grid, st, p);
+      else launch_stats<FMT, false>(scope, nv, team_log2, grid, st, p);
+      return;
+    }
+  }
   if (scope == SC_SUBWAVE) {
     if constexpr (SEL == SEL_STATS_ONLY) {
       if (nv == -4) {  // L = 32 * 2^team_log2: four vectors of one segment per lane
@@ -1562,13 +1908,30 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   }
   // statistics only: the kernels compiled without the output stores
   const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
+  const bool stats_kernels = kmode == SEL_STATS_ONLY && vec_ok && (w_dtype == MQ_F16 || w_dtype == MQ_BF16);
   if (kmode == SEL_STATS_ONLY && scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0 && !sampled) {
-    // groups of 32 * 2^k elements: the kernel that holds four vectors of one segment per lane
+    // groups of 32 * 2^k elements: the kernels that hold four vectors of one segment per lane
     team_log2 = ilog2_ceil(p.L / 32);
     nv = -4;
+    if (stats_kernels) scope = SC_STATS_GROUP;
     const int64_t spw = 64 >> team_log2;
     const int64_t wb = ((p.nseg + spw - 1) / spw + 3) / 4;
     grid.x = (unsigned)(wb < max_grid ? wb : max_grid);
+  } else if (stats_kernels && (scope == SC_WAVE || scope == SC_BLOCK) && p.L / 8 <= 4096) {
+    const int64_t vecs = p.L / 8;
+    int64_t wb;
+    if (vecs <= 1024) {  // one wave per row
+      scope = SC_STATS_ROW;
+      nv = vecs <= 128 ? 2 : vecs <= 256 ? 4 : vecs <= 512 ? 8 : vecs <= 768 ? 12 : 16;
+      wb = (p.nseg + 3) / 4;
+    } else {             // one 256-thread workgroup per row
+      scope = SC_STATS_ROWBLK;
+      nv = vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
+      wb = p.nseg;
+    }
+    int64_t cap = grid_cap();
+    if (count > 1) cap = cap / count < 64 ? 64 : cap / count;
+    grid.x = (unsigned)(wb < cap ? wb : cap);
   }
   switch (fmt) {
     case MQ_INT_SYM: mq_launch_fmt1(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;

@@ -1,0 +1,77 @@
+// Read floor of the statistics-only passes: 16 bytes per lane per load, nothing stored.  Variants: grid size,
+// vectors in flight per lane, plain vs non-temporal loads, contiguous 1 KiB per wave instruction vs the
+// "four vectors of one 64-byte run per lane" pattern of k_quant_team4<T = 1>, and a dummy VALU load of
+// WORK packed instructions per 8-element vector to see how much arithmetic hides under the memory time.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NV, int WORK, bool NT, bool RUN64>
+__global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ w, uint32_t* __restrict__ out, int64_t nvec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  const int64_t tiles = nvec / (64 * NV);
+  auto ld = [&](int64_t t, int j) {
+    const int64_t v = RUN64 ? (t * 64 + lane) * NV + j : (t * NV + j) * 64 + lane;
+    return NT ? __builtin_nontemporal_load(&w[v]) : w[v];
+  };
+  u32x4 nxt[NV];
+  if (gw < tiles)
+    for (int j = 0; j < NV; ++j) nxt[j] = ld(gw, j);
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  for (int64_t t = gw; t < tiles; t += nw) {
+    u32x4 raw[NV];
+    for (int j = 0; j < NV; ++j) raw[j] = nxt[j];
+    if (t + nw < tiles)
+      for (int j = 0; j < NV; ++j) nxt[j] = ld(t + nw, j);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      u32x4 r = raw[j];
+      a0 ^= r[0]; a1 ^= r[1]; a2 ^= r[2]; a3 ^= r[3];
+#pragma unroll
+      for (int k = 0; k < WORK / 4; ++k) {
+        asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %5\n v_pk_add_u16 %2, %2, %6\n v_pk_add_u16 %3, %3, %7"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+      }
+    }
+  }
+  uint32_t a = a0 ^ a1 ^ a2 ^ a3;
+  if (a == 0x12345678u) out[threadIdx.x] = a;
+}
+
+int main() {
+  const int64_t n = 16ll * 4096 * 4096, nvec = n / 8;
+  void *w, *out;
+  hipMalloc(&w, n * 2); hipMalloc(&out, 4096);
+  hipMemset(w, 1, n * 2);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const double bytes = n * 2.0;
+  auto run = [&](const char* name, auto kern, int grid) {
+    float best = 1e9;
+    for (int rep = 0; rep < 6; ++rep) {
+      hipEventRecord(e0);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const u32x4*)w, (uint32_t*)out, nvec);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+    }
+    printf("%-34s grid %5d  %7.1f us  %6.2f TB/s\n", name, grid, best * 1e3, bytes / best / 1e9);
+  };
+  for (int grid : {1024, 2048, 4096, 8192, 16384, 32768}) {
+    run("NV4 contiguous", k_read<4, 0, false, false>, grid);
+    run("NV4 contiguous nt", k_read<4, 0, true, false>, grid);
+    run("NV8 contiguous", k_read<8, 0, false, false>, grid);
+    run("NV2 contiguous", k_read<2, 0, false, false>, grid);
+    run("NV4 64-byte runs per lane", k_read<4, 0, false, true>, grid);
+  }
+  for (int grid : {4096, 8192}) {
+    run("NV4 + 16 VALU / vector", k_read<4, 16, false, false>, grid);
+    run("NV4 + 32 VALU / vector", k_read<4, 32, false, false>, grid);
+    run("NV4 + 48 VALU / vector", k_read<4, 48, false, false>, grid);
+    run("NV4 + 64 VALU / vector", k_read<4, 64, false, false>, grid);
+    run("NV4 + 80 VALU / vector", k_read<4, 80, false, false>, grid);
+    run("NV4 + 96 VALU / vector", k_read<4, 96, false, false>, grid);
+    run("NV4 runs + 64 VALU / vector", k_read<4, 64, false, true>, grid);
+  }
+  return 0;
+}

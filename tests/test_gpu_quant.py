@@ -396,8 +396,9 @@ def test_quant_model_batched_equals_per_layer(qa):
 @pytest.mark.parametrize("fmt", ["int8", "int8_asym", "fp8_e4m3", "fp4"])
 def test_statistics_only_mode_equals_general_mode(qa, fmt):
     """Without any element-sized output the kernels compiled without the stores run (the model sweeps): scales
-    and zero-points must have the bits the general kernels produce, per-segment and per-tensor sums the same value
-    up to the order of the float64 additions."""
+    and zero-points must have the bits the general kernels produce; per-segment and per-tensor sums agree to the
+    1e-6 bar (this mode adds a lane's 8 exact float32 squares with v_dot2_f32_f16, the general kernels pairwise;
+    everything above a lane is float64 in both)."""
     from quantization_amd import _lib
     from quantization_amd.fused import quantize, quantize_batch
     code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
@@ -418,9 +419,9 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
         assert torch.equal(full.scale.view(torch.int16), stats.scale.view(torch.int16)), what
         if code == _lib.INT_ASYM:
             assert torch.equal(full.zero_point.view(torch.int16), stats.zero_point.view(torch.int16)), what
-        # (same float32 squares; the group kernel of this mode adds them in another float64 order)
-        torch.testing.assert_close(stats.seg_sse, full.seg_sse, rtol=1e-13, atol=0)
-        torch.testing.assert_close(stats.totals, full.totals, rtol=1e-13, atol=0)
+        # (same float32 squares, added in another order: at most 4 float32 roundings per lane)
+        torch.testing.assert_close(stats.seg_sse, full.seg_sse, rtol=1e-6, atol=0)
+        torch.testing.assert_close(stats.totals, full.totals, rtol=5e-7, atol=0)
         # and the error sums belong to the dequantized values the general kernel returned
         err = (w.to(torch.float16).float() - full.deq.float())
         want = (err * err).double().sum().item()
@@ -428,5 +429,5 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
     w3 = (torch.randn(5, 256, 1024) * 0.02).half().cuda()
     b_full = quantize_batch(w3, code, bits, 128, table, deq=True, codes=False, scale=True, seg_sse=True, totals=True)
     b_stats = quantize_batch(w3, code, bits, 128, table, deq=False, codes=False, scale=False, seg_sse=True, totals=True)
-    torch.testing.assert_close(b_stats.seg_sse, b_full.seg_sse, rtol=1e-13, atol=0)
-    torch.testing.assert_close(b_stats.totals, b_full.totals, rtol=1e-13, atol=0)
+    torch.testing.assert_close(b_stats.seg_sse, b_full.seg_sse, rtol=1e-6, atol=0)
+    torch.testing.assert_close(b_stats.totals, b_full.totals, rtol=5e-7, atol=0)
