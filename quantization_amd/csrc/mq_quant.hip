@@ -146,6 +146,12 @@ struct SegP {
     asm(insn " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                 \
     return r;                                                           \
   }
+#define MQ_PK_OP3(name, insn)                                                      \
+  __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b, uint32_t c) {  \
+    uint32_t r;                                                                   \
+    asm(insn " %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));               \
+    return r;                                                                     \
+  }
 MQ_PK_OP(pk_min_f16, "v_pk_min_f16")
 MQ_PK_OP(pk_max_f16, "v_pk_max_f16")
 MQ_PK_OP(pk_min_u16, "v_pk_min_u16")
@@ -157,6 +163,10 @@ __device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) {
   asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+__device__ __forceinline__ uint32_t pk_shr_u16(uint32_t sh, uint32_t v);
+// NaN-propagating packed float16 max / min of three (gfx950): a NaN operand gives a NaN half, -0 < +0
+MQ_PK_OP3(pk_maximum3_f16, "v_pk_maximum3_f16")
+MQ_PK_OP3(pk_minimum3_f16, "v_pk_minimum3_f16")
 __device__ __forceinline__ h16x2 as_h2(uint32_t w) { return __builtin_bit_cast(h16x2, w); }
 __device__ __forceinline__ uint32_t as_u32(h16x2 h) { return __builtin_bit_cast(uint32_t, h); }
 __device__ __forceinline__ uint32_t dup16(uint32_t b) { return (b & 0xffffu) | (b << 16); }
@@ -529,44 +539,59 @@ __device__ __forceinline__ float mix_rem_hi(float q0, float s, uint32_t vw) {
 __device__ __forceinline__ h16x2 div_pk(uint32_t vw, const SegP& sp) {
   const float q0a = mix_mul_lo(vw, sp.r), q0b = mix_mul_hi(vw, sp.r);
   const float ra = mix_rem_lo(q0a, sp.sf, vw), rb = mix_rem_hi(q0b, sp.sf, vw);
-  const h16x2 x = {(half_t)__builtin_fmaf(ra, sp.r, q0a), (half_t)__builtin_fmaf(rb, sp.r, q0b)};
-  return x;
+  // (written as an instruction: from a plain conversion of the two fma results the compiler forms
+  //  v_fma_mixlo_f16 + v_fma_mixhi_f16, which issue at 8 cycles each against 2.6 + 2.6 + 4.2 for this form)
+  uint32_t x;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_fmaf(ra, sp.r, q0a)), "v"(__builtin_fmaf(rb, sp.r, q0b)));
+  return as_h2(x);
 }
-// sse += e.lo^2 + e.hi^2;  sabs += |e.lo| + |e.hi|
-__device__ __forceinline__ void err_dot2(h16x2 e, float& sse, float& sabs) {
-  sse = __builtin_amdgcn_fdot2(e, e, sse, false);
-  sabs = __builtin_amdgcn_fdot2(as_h2(as_u32(e) & 0x7fff7fffu), as_h2(0x3c003c00u), sabs, false);
+// |nearest table value| for the two float16 quotients in xw, for a table WITHOUT subnormals; vw: the weights (the
+// quotient has their sign, and a zero quotient rounds to zero whatever its sign).  lut_round_pk without the sign
+// handling and without the upper clamp: the caller knows |x| <= (1 + 2^-9) * largest entry, which rounds to the
+// largest entry for up to 6 mantissa bits (the host sends tables with more to the general kernels).
+__device__ __forceinline__ uint32_t lut_round_mag_pk(uint32_t xw, uint32_t vw, const LutConst& c) {
+  const uint32_t an = (xw & 0x7fff7fffu) + pk_shr_u16(dup16(15u), vw);  // |x| bits, + 1 for negative x
+  uint32_t r = (an + dup16(c.half - 1u)) & dup16(0xffffu << c.shift);
+  r = pk_max_u16(r, dup16(c.minpos));
+  uint32_t t;  // mid - an per half: negative iff |x| is past the 0 / minpos midpoint
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(t) : "v"(dup16(c.mid)), "v"(an));
+  uint32_t m;  // (the shift count from a register: an inline constant would reach the low half only)
+  asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(dup16(15u)), "v"(t));
+  return r & m;
 }
-
-// One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements (the caller carries
-// everything above that in float64).
+// One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements are ADDED to the caller's
+// (the caller carries everything above a few vectors in float64).
 template <int FMT>
 __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 raw, const SegP& sp, float& sse,
                                              float& sabs) {
   const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
-  sse = 0.f;
-  sabs = 0.f;
+  float q = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t vw = raw[k];
     const h16x2 x = div_pk(vw, sp);
-    h16x2 d;
+    h16x2 e;
     if constexpr (FMT == MQ_INT_SYM) {
-      d = ((x + magic) - magic) * s2;
+      e = as_h2(vw) - ((x + magic) - magic) * s2;
     } else if constexpr (FMT == MQ_INT_ASYM) {
       // clamp(rint(x) + zp, 0, qmax) - zp = clamp(rint(x), -zp, qmax - zp): every value is an integer below 2048,
       // so the float16 additions are exact; the clamp is applied to 1536 + rint(x)
       const h16x2 zp2 = as_h2(dup16(h_bits(sp.zp)));
       const h16x2 lo = magic - zp2, hi = lo + as_h2(dup16(h_bits((half_t)p.qmax)));
       uint32_t t = pk_min_f16(pk_max_f16(as_u32(x + magic), as_u32(lo)), as_u32(hi));
-      d = (as_h2(t) - magic) * s2;
+      e = as_h2(vw) - (as_h2(t) - magic) * s2;
+    } else if constexpr (FMT == MQ_LUT_FP) {
+      // magnitudes: |e| = | |v| - |q| s |, the table value has the sign of v or is zero
+      const uint32_t qm = lut_round_mag_pk(as_u32(x), vw, p.lut);
+      e = as_h2(vw & 0x7fff7fffu) - as_h2(qm) * s2;
     } else {
-      uint32_t qw = FMT == MQ_LUT_FP_SUB ? lut_round_pk_sub(as_u32(x), p.lut) : lut_round_pk(as_u32(x), p.lut);
-      d = as_h2(qw) * s2;
+      e = as_h2(vw) - as_h2(lut_round_pk_sub(as_u32(x), p.lut)) * s2;
     }
-    err_dot2(as_h2(vw) - d, sse, sabs);
+    q = __builtin_amdgcn_fdot2(e, e, q, false);
+    sabs = __builtin_amdgcn_fdot2(as_h2(as_u32(e) & 0x7fff7fffu), as_h2(0x3c003c00u), sabs, false);
   }
+  sse += q;
 }
 
 // Fast path: packed float16 arithmetic, exact for finite data with |v / s| < 512.
@@ -577,7 +602,7 @@ template <int FMT, int SEL>
 __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 raw, const SegP& sp, int64_t e0,
                                               Acc& acc) {
   if constexpr (SEL == SEL_STATS_ONLY) {
-    float sse, sabs;
+    float sse = 0.f, sabs = 0.f;
     quant8_stats<FMT>(p, raw, sp, sse, sabs);
     acc.abs += (double)sabs;
     return (double)sse;
@@ -1078,70 +1103,118 @@ __device__ __forceinline__ u32x4 stats_cvt(u32x4 raw) {
   if constexpr (BF16) return bf16x8_to_f16(raw);
   else return raw;
 }
-// one lane's reduction word over NV vectors: absmax bits, or (min | max << 16)
+#ifndef MQ_STATS_NT
+#define MQ_STATS_NT 1  // weights are read once: non-temporal loads (measured 7.0 against 6.3 TB/s for a plain read)
+#endif
+__device__ __forceinline__ u32x4 stats_load(const char* ptr) {
+#if MQ_STATS_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+#else
+  return *reinterpret_cast<const u32x4*>(ptr);
+#endif
+}
+// One lane's reduction word over NV vectors: absmax bits, or (min | max << 16).  v_pk_maximum3 / minimum3_f16 take
+// two new words per instruction and, unlike v_pk_max / min_f16, return a NaN when an operand is one (a NaN in the
+// segment must reach the parameters: torch.amax / amin propagate it).
 template <int FMT, int NV>
 __device__ __forceinline__ uint32_t stats_lane_reduce(const u32x4* raw) {
-  if constexpr (FMT == MQ_INT_ASYM) {
-    uint32_t lo = raw[0][0], hi = raw[0][0];
+  uint32_t mx = raw[0][0], mn = raw[0][0];
 #pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (j == 0 && k == 0) continue;
-        lo = pk_min_f16(lo, raw[j][k]);
-        hi = pk_max_f16(hi, raw[j][k]);
-      }
-    return fold_minmax(lo, hi);
-  } else {
-    uint32_t m2 = 0;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m2 = pk_max_u16(m2, raw[j][k] & 0x7fff7fffu);
-    return fold_max_u16(m2);
+  for (int i = 1; i + 1 < 4 * NV; i += 2) {
+    mx = pk_maximum3_f16(mx, raw[i >> 2][i & 3], raw[(i + 1) >> 2][(i + 1) & 3]);
+    mn = pk_minimum3_f16(mn, raw[i >> 2][i & 3], raw[(i + 1) >> 2][(i + 1) & 3]);
   }
+  const uint32_t last = raw[NV - 1][3];  // 4 NV - 1 words follow the first: an odd count
+  mx = pk_maximum3_f16(mx, last, last);
+  mn = pk_minimum3_f16(mn, last, last);
+  if constexpr (FMT == MQ_INT_ASYM) {
+    // (mn.l, mx.l) vs (mn.h, mx.h): min of the low halves, max of the high halves
+    const uint32_t a = (mn & 0xffffu) | (mx << 16), c = (mn >> 16) | (mx & 0xffff0000u);
+    return (pk_minimum3_f16(a, c, c) & 0xffffu) | (pk_maximum3_f16(a, c, c) & 0xffff0000u);
+  } else {
+    return fold_max_u16(pk_max_u16(mx & 0x7fff7fffu, mn & 0x7fff7fffu));  // integer max: a NaN wins
+  }
+}
+__device__ __forceinline__ uint32_t op_minmax_nan(uint32_t a, uint32_t b) {
+  return (pk_minimum3_f16(a, b, b) & 0xffffu) | (pk_maximum3_f16(a, b, b) & 0xffff0000u);
 }
 template <int FMT>
 __device__ __forceinline__ uint32_t stats_op(uint32_t a, uint32_t b) {
-  if constexpr (FMT == MQ_INT_ASYM) return op_minmax(a, b);
+  if constexpr (FMT == MQ_INT_ASYM) return op_minmax_nan(a, b);
   else return op_max_u32(a, b);
 }
+// params_absmax / params_minmax with the common case in few instructions: h(a / qmax) by the reciprocal multiply
+// in mixed precision when the host has verified it for this qmax, the clamp as v_max / v_min_f16.
 template <int FMT>
 __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p) {
-  if constexpr (FMT == MQ_INT_ASYM) return params_minmax(red, p);
-  else return params_absmax(red, p);
-}
-// NV vectors of one segment held by this lane -> float64 sum of squared errors; acc_abs += sum |error|
-template <int FMT, int NV>
-__device__ __forceinline__ double stats_vectors(const QuantParams& p, const u32x4* raw, const SegP& sp, bool any_slow,
-                                                double& acc_abs) {
-  double s = 0.0;
-  if (__builtin_expect(any_slow, 0)) {
-    Acc acc;
-    acc.abs = 0.0;
-    acc.xp = nullptr;
-#pragma unroll 1
-    for (int j = 0; j < NV; ++j) {
-      // (a rolled loop with a run-time index would move raw[] to scratch memory: select the vector instead)
-      u32x4 v = raw[0];
-#pragma unroll
-      for (int i = 1; i < NV; ++i) v = i == j ? raw[i] : v;
-      s += sp.slow ? quant8_slow<FMT, SEL_STATS_ONLY>(p, v, sp, 0, acc) : quant8_fast<FMT, SEL_STATS_ONLY>(p, v, sp, 0, acc);
-    }
-    acc_abs += acc.abs;
-    return s;
+  if (!p.qmax_recip_ok) {
+    if constexpr (FMT == MQ_INT_ASYM) return params_minmax(red, p);
+    else return params_absmax(red, p);
   }
-  float ab = 0.f;
+  const half_t lo = h_from_bits(0x00A8u), hi = h_from_bits(0x70E2u);
+  SegP sp;
+  if constexpr (FMT == MQ_INT_ASYM) {
+    const half_t rmin = h_from_bits(red & 0xffffu), rmax = h_from_bits(red >> 16);
+    const uint32_t range = h_bits(rmax - rmin);
+    const float q0 = mix_mul_lo(range, p.rqmax);
+    const half_t s0 = (half_t)__builtin_fmaf(mix_rem_lo(q0, p.qmax, range), p.rqmax, q0);
+    finish_params(sp, __builtin_fminf16(__builtin_fmaxf16(s0, lo), hi));
+    const half_t qmax_h = (half_t)p.qmax;
+    half_t z = __builtin_rintf16(div_h_full(-(float)rmin, sp));  // (a -0 stays -0, as torch.clamp leaves it)
+    z = z < (half_t)0 ? (half_t)0 : z;
+    sp.zp = z > qmax_h ? qmax_h : z;
+    const float big = __builtin_fmaxf(__builtin_fabsf((float)rmin), __builtin_fabsf((float)rmax));
+    // the fast path needs finite data, |v / s| < 512, a scale below the upper clamp and -- for the exact float16
+    // error of quant8_stats -- a row that does not lie on one side of zero (then the clamp to [0, qmax] removes
+    // at most one step from a code, see tests/tools/sterbenz_exhaustive.c)
+    sp.slow = !(big * sp.r < 500.0f) || !((float)h_from_bits(range) < 65504.0f) || s0 > hi || !(s0 == s0) ||
+              (float)rmin > 0.f || (float)rmax < 0.f;
+    if (sp.slow) sp = params_minmax(red, p);
+    sp.slow = sp.slow || s0 > hi || (float)rmin > 0.f || (float)rmax < 0.f;
+  } else {
+    const float q0 = mix_mul_lo(red, p.rqmax);
+    const half_t s0 = (half_t)__builtin_fmaf(mix_rem_lo(q0, p.qmax, red), p.rqmax, q0);
+    finish_params(sp, __builtin_fminf16(__builtin_fmaxf16(s0, lo), hi));
+    sp.zp = (half_t)0;
+    // inf / NaN in the segment, or a scale cut by the upper clamp (then |v / s| may pass qmax)
+    sp.slow = red >= 0x7c00u || s0 > hi;
+    if (sp.slow) { sp = params_absmax(red, p); sp.slow = true; }
+  }
+  return sp;
+}
+// NV vectors of one segment held by this lane (fast path) -> float64 sum of squared errors, sum of |error|
+template <int FMT, int NV>
+__device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4* raw, const SegP& sp, double& sse,
+                                              double& sabs) {
+  // float32 within two vectors (squares: 8 dot steps + 1 add) resp. four vectors (|error|), float64 above
+  sse = 0.0;
+  sabs = 0.0;
+  float q = 0.f, ab = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    float q, a;
-    quant8_stats<FMT>(p, raw[j], sp, q, a);
-    s += (double)q;
-    // |error| sums of up to 4 vectors (16 dot steps) stay in float32
-    ab += a;
-    if ((j & 3) == 3 || j == NV - 1) { acc_abs += (double)ab; ab = 0.f; }
+    quant8_stats<FMT>(p, raw[j], sp, q, ab);
+    if ((j & 1) == 1 || j == NV - 1) { sse += (double)q; q = 0.f; }
+    if ((j & 3) == 3 || j == NV - 1) { sabs += (double)ab; ab = 0.f; }
+    // one vector's arithmetic at a time: interleaving all NV of them costs 100+ registers of temporaries
+    __builtin_amdgcn_sched_barrier(0);
   }
-  return s;
+}
+// Segments off the fast path (inf / NaN, a clamped scale, asymmetric rows on one side of zero ...) are rare and
+// their per-element code is register-hungry.  The main loops skip them (no stores, nothing added to the sums) and
+// remember that one was seen; a second loop after the main one -- whose registers the prefetch buffers no longer
+// occupy -- walks the same segments again and handles only those.  count vectors, stride bytes apart, starting
+// at first.
+template <int FMT>
+__device__ __forceinline__ void stats_slow_segment(const QuantParams& p, const SegP& sp, const char* first, int count,
+                                                   int stride, double& sse, double& sabs) {
+  Acc acc;
+  acc.abs = 0.0;
+  acc.xp = nullptr;
+  sse = 0.0;
+#pragma unroll 1
+  for (int j = 0; j < count; ++j)
+    sse += quant8_slow<FMT, SEL_STATS_ONLY>(p, load8_f16(first + (int64_t)j * stride, p.in_dtype, 0), sp, 0, acc);
+  sabs = acc.abs;
 }
 
 template <int FMT, bool BF16, int T>
@@ -1156,30 +1229,24 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   const char* wb = static_cast<const char*>(p.w);
   const uint32_t loff = (uint32_t)(team * (64 * T) + tl * 16);  // this lane's bytes inside the step's 4 KiB
   double acc_sse = 0.0, acc_abs = 0.0;
-  u32x4 nxt[NV];
-  auto issue = [&](int64_t t) {
+  bool seen_slow = false;
+  auto issue = [&](int64_t t, u32x4* dst) __attribute__((always_inline)) {
     const char* sb = wb + t * 4096 + loff;
     if (t < full) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) nxt[j] = *reinterpret_cast<const u32x4*>(sb + j * (16 * T));
+      for (int j = 0; j < NV; ++j) dst[j] = stats_load(sb + j * (16 * T));
     } else {  // the last, partial step
       const bool in = t * SPW + team < p.nseg;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) nxt[j] = in ? *reinterpret_cast<const u32x4*>(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
+      for (int j = 0; j < NV; ++j) dst[j] = in ? stats_load(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
     }
   };
-  if (gw < steps) issue(gw);
-  for (int64_t t = gw; t < steps; t += nwaves) {
-    u32x4 raw[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(nxt[j]);
-    if (t + nwaves < steps) issue(t + nwaves);
+  auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take) __attribute__((always_inline)) {
     const int64_t seg = t * SPW + team;
-    const bool valid = t < full || seg < p.nseg;
-    const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
-    const bool any_slow = __builtin_amdgcn_ballot_w64(sp.slow) != 0;
-    double s = stats_vectors<FMT, NV>(p, raw, sp, any_slow, acc_abs);  // (an invalid lane holds zeros: no error)
+    const bool valid = (t < full || seg < p.nseg) && take;
+    s = take ? s : 0.0;
     acc_sse += s;
+    acc_abs += take ? ab : 0.0;
     if (p.seg_sse) {
       s = team_sum<T>(s);
       if (valid && tl == 0) p.seg_sse[seg] = s;
@@ -1187,6 +1254,46 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     if (valid && tl == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
       if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+    }
+  };
+  auto step = [&](int64_t t, const u32x4* buf) __attribute__((always_inline)) {
+    u32x4 raw[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(buf[j]);
+    const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
+    seen_slow = seen_slow || sp.slow;
+    double s, ab;
+    stats_vectors<FMT, NV>(p, raw, sp, s, ab);  // (a lane past the end holds zeros: no error)
+    finish(t, sp, s, ab, !sp.slow);
+  };
+  // two register buffers take turns, so that the next step's loads are in flight while this one is computed and
+  // no vector is copied between registers
+  {
+    u32x4 bufa[NV], bufb[NV];
+    int64_t t = gw;
+    if (t < steps) issue(t, bufa);
+    while (t < steps) {
+      const int64_t t1 = t + nwaves, t2 = t1 + nwaves;
+      if (t1 < steps) issue(t1, bufb);
+      step(t, bufa);
+      if (t1 >= steps) break;
+      if (t2 < steps) issue(t2, bufa);
+      step(t1, bufb);
+      t = t2;
+    }
+  }
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(seen_slow) != 0, 0)) {
+#pragma unroll 1
+    for (int64_t t = gw; t < steps; t += nwaves) {
+      u32x4 raw[NV];
+      issue(t, raw);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
+      const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
+      if (__builtin_amdgcn_ballot_w64(sp.slow) == 0) continue;
+      double s = 0.0, ab = 0.0;
+      if (sp.slow) stats_slow_segment<FMT>(p, sp, wb + t * 4096 + loff, (t < full || t * SPW + team < p.nseg) ? NV : 0, 16 * T, s, ab);
+      finish(t, sp, s, ab, sp.slow);
     }
   }
   block_partials(p, acc_sse, acc_abs, lds);
@@ -1196,8 +1303,10 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
 // (j * WPR + w) * 64 + l, j < NV, so every load instruction of a wave reads 1 KiB of consecutive bytes.  Vectors
 // past the end of a row (rows that are not a multiple of 512 * NV * WPR elements) are loaded as zeros: they
 // change neither the absolute maximum nor the error sums (min / max skip them explicitly).
+// (The second launch bound -- waves per SIMD -- and the scheduling barriers of stats_vectors keep the compiler from
+//  interleaving all NV vectors' arithmetic, which took 160 .. 220 registers.)
 template <int FMT, bool BF16, int NV, int WPR>
-__global__ __launch_bounds__(256) void k_stats_row(const QuantBatch b) {
+__global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   __shared__ uint32_t xr[2][4];
@@ -1211,45 +1320,30 @@ __global__ __launch_bounds__(256) void k_stats_row(const QuantBatch b) {
   const int64_t row_bytes = p.L * 2;
   const uint32_t loff = (uint32_t)(sub * 1024 + lane * 16);
   const bool whole = p.vecs_per_seg == 64 * NV * WPR;  // no vector of the grid lies past the row's end
-  constexpr bool PREFETCH = NV <= 8;
   double acc_sse = 0.0, acc_abs = 0.0;
-  u32x4 nxt[PREFETCH ? NV : 1];
-  auto issue = [&](int64_t row, u32x4* dst) {
+  int parity = 0;
+  bool seen_slow = false;
+  auto issue = [&](int64_t row, u32x4* dst) __attribute__((always_inline)) {
     const char* sb = wb + row * row_bytes + loff;
     if (whole) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = *reinterpret_cast<const u32x4*>(sb + j * (1024 * WPR));
+      for (int j = 0; j < NV; ++j) dst[j] = stats_load(sb + j * (1024 * WPR));
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j)
-        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? *reinterpret_cast<const u32x4*>(sb + j * (1024 * WPR))
-                                                              : u32x4{0, 0, 0, 0};
+        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? stats_load(sb + j * (1024 * WPR)) : u32x4{0, 0, 0, 0};
     }
   };
-  if constexpr (PREFETCH) {
-    if (first < p.nseg) issue(first, nxt);
-  }
-  int parity = 0;
-  for (int64_t row = first; row < p.nseg; row += stride) {
-    u32x4 raw[NV];
-    if constexpr (PREFETCH) {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(nxt[j]);
-      if (row + stride < p.nseg) issue(row + stride, nxt);
-    } else {
-      issue(row, raw);
-#pragma unroll
-      for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
-    }
+  // this row's parameters from the lane's vectors (every wave of the row gets the same)
+  auto row_params = [&](const u32x4* raw) __attribute__((always_inline)) {
     uint32_t red = stats_lane_reduce<FMT, NV>(raw);
     if constexpr (FMT == MQ_INT_ASYM) {
       if (!whole) {  // the zeros past the row's end must not enter min / max
         red = 0xfc007c00u;  // (+inf, -inf): neutral
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-          uint32_t lo, hi;
-          minmax8_pk(raw[j], lo, hi);
-          if ((j * WPR + sub) * 64 + lane < p.vecs_per_seg) red = op_minmax(red, fold_minmax(lo, hi));
+          u32x4 one[1] = {raw[j]};
+          if ((j * WPR + sub) * 64 + lane < p.vecs_per_seg) red = op_minmax_nan(red, stats_lane_reduce<FMT, 1>(one));
         }
       }
     }
@@ -1260,9 +1354,11 @@ __global__ __launch_bounds__(256) void k_stats_row(const QuantBatch b) {
 #pragma unroll
       for (int i = 0; i < WPR; ++i) red = stats_op<FMT>(red, xr[parity][i]);
     }
-    const SegP sp = stats_params<FMT>(red, p);
-    double s = stats_vectors<FMT, NV>(p, raw, sp, sp.slow, acc_abs);
+    return stats_params<FMT>(red, p);
+  };
+  auto finish = [&](int64_t row, const SegP& sp, double s, double ab) __attribute__((always_inline)) {
     acc_sse += s;
+    acc_abs += ab;
     if (p.seg_sse) {
       s = team_sum<64>(s);
       if constexpr (WPR > 1) {
@@ -1282,7 +1378,63 @@ __global__ __launch_bounds__(256) void k_stats_row(const QuantBatch b) {
       if (p.scale) p.scale[row] = (uint16_t)h_bits(sp.s);
       if (FMT == MQ_INT_ASYM && p.zp) p.zp[row] = (uint16_t)h_bits(sp.zp);
     }
+  };
+  auto step = [&](int64_t row, const u32x4* buf) __attribute__((always_inline)) {
+    u32x4 raw[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(buf[j]);
+    const SegP sp = row_params(raw);
+    if (__builtin_expect(sp.slow, 0)) {  // (uniform over the row's waves: no barrier is skipped by some of them)
+      seen_slow = true;
+    } else {
+      double s, ab;
+      stats_vectors<FMT, NV>(p, raw, sp, s, ab);
+      finish(row, sp, s, ab);
+    }
     parity ^= 1;
+  };
+  if constexpr (NV <= 8) {
+    // two register buffers take turns: the next row's loads are in flight while this one is computed
+    u32x4 bufa[NV], bufb[NV];
+    int64_t row = first;
+    if (row < p.nseg) issue(row, bufa);
+    while (row < p.nseg) {
+      const int64_t r1 = row + stride, r2 = r1 + stride;
+      if (r1 < p.nseg) issue(r1, bufb);
+      step(row, bufa);
+      if (r1 >= p.nseg) break;
+      if (r2 < p.nseg) issue(r2, bufa);
+      step(r1, bufb);
+      row = r2;
+    }
+  } else {
+    for (int64_t row = first; row < p.nseg; row += stride) {
+      u32x4 buf[NV];
+      issue(row, buf);
+      step(row, buf);
+    }
+  }
+  if (__builtin_expect(seen_slow, 0)) {
+#pragma unroll 1
+    for (int64_t row = first; row < p.nseg; row += stride) {
+      SegP sp;
+      {
+        u32x4 raw[NV];
+        issue(row, raw);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
+        sp = row_params(raw);
+      }
+      if (sp.slow) {
+        int count = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) count += (j * WPR + sub) * 64 + lane < p.vecs_per_seg;
+        double s, ab;
+        stats_slow_segment<FMT>(p, sp, wb + row * row_bytes + loff, count, 1024 * WPR, s, ab);
+        finish(row, sp, s, ab);
+      }
+      parity ^= 1;
+    }
   }
   block_partials(p, acc_sse, acc_abs, lds);
 }
@@ -1908,7 +2060,9 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   }
   // statistics only: the kernels compiled without the output stores
   const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
-  const bool stats_kernels = kmode == SEL_STATS_ONLY && vec_ok && (w_dtype == MQ_F16 || w_dtype == MQ_BF16);
+  // (tables without subnormals and more than 6 mantissa bits need the upper clamp lut_round_mag_pk leaves out)
+  const bool stats_kernels = kmode == SEL_STATS_ONLY && vec_ok && (w_dtype == MQ_F16 || w_dtype == MQ_BF16) &&
+                             !(fmt == MQ_LUT_FP && cfg->man_bits > 6);
   if (kmode == SEL_STATS_ONLY && scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0 && !sampled) {
     // groups of 32 * 2^k elements: the kernels that hold four vectors of one segment per lane
     team_log2 = ilog2_ceil(p.L / 32);

@@ -23,7 +23,9 @@ __global__ void k_probe(const uint32_t* in, float* dot2, float* dot2c, float* mi
   asm volatile("v_fma_mix_f32 %0, |%1|, %2, %3 op_sel_hi:[1,1,0]" : "=v"(m) : "v"(w), "v"(one), "v"(acc));
   mix[i] = m;
   uint32_t z = 0, q;
-  asm volatile("v_max3_f16 %0, |%1|, |%1|, %2 op_sel:[0,1,0,0]" : "=v"(q) : "v"(w), "v"(z));
+  // packed maximum3 of (w, w swapped, 0): both halves hold max(lo, hi, 0) if NaN-free
+  uint32_t sw = (w >> 16) | (w << 16);
+  asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(q) : "v"(w), "v"(sw), "v"(z));
   mx[i] = q;
 }
 
@@ -68,9 +70,10 @@ int main() {
     }
     // max3(|lo|, |hi|, 0): report the NaN behaviour
     bool nan_in = (((lo >> 10) & 31) == 31 && (lo & 1023)) || (((hi >> 10) & 31) == 31 && (hi & 1023));
-    uint32_t al = lo & 0x7fff, ah = hi & 0x7fff;
     if (!nan_in) {
-      uint32_t want = al > ah ? al : ah;
+      float fa = h2f(lo), fb = h2f(hi);
+      float fm = fa > fb ? fa : fb; if (!(fm > 0.f)) fm = 0.f;
+      uint32_t want = 0; for (uint32_t c = 0; c < 0x7c01; ++c) if (h2f(c) == fm) { want = c; break; }
       if ((rx[i] & 0xffff) != want) { ++badx; if (badx <= 5) printf("max3 lo %04x hi %04x got %04x want %04x\n", lo, hi, rx[i] & 0xffff, want); }
     }
   }
@@ -79,8 +82,8 @@ int main() {
   // NaN behaviour samples
   for (int i = 0; i < n; ++i) {
     uint32_t lo = h[i] & 0xffff, hi = h[i] >> 16;
-    if ((lo == 0x7e00 && hi == 0x3c00) || (lo == 0x3c00 && hi == 0x7e00) || (lo == 0x7d01 && hi == 0x3c00) || (lo == 0xfe00 && hi == 0x7c00))
-      printf("max3(|%04x|,|%04x|,0) = %04x   dot2 = %a\n", lo, hi, rx[i] & 0xffff, r2[i]);
+    if ((lo == 0x7e00 && hi == 0xbc00) || (lo == 0x3c00 && hi == 0x7d01) || (lo == 0x7e00 && hi == 0x3c00) || (lo == 0x3c00 && hi == 0x7e00) || (lo == 0x7d01 && hi == 0x3c00) || (lo == 0xfe00 && hi == 0x7c00))
+      printf("pk_maximum3(%04x,%04x,0) = %04x   dot2 = %a\n", lo, hi, rx[i] & 0xffff, r2[i]);
   }
   return 0;
 }

@@ -60,6 +60,19 @@ KERNEL(k_pk_max_f16, "v_pk_max_f16 %0, %6, %7\n v_pk_max_f16 %1, %6, %8\n v_pk_m
 KERNEL(k_max3_u32, "v_max3_u32 %0, %6, %7, %0\n v_max3_u32 %1, %6, %8, %1\n v_max3_u32 %2, %6, %9, %2\n v_max3_u32 %3, %7, %8, %3\n")
 KERNEL(k_and_or_b32, "v_and_or_b32 %0, %6, %7, %8\n v_and_or_b32 %1, %6, %8, %9\n v_and_or_b32 %2, %6, %9, %7\n v_and_or_b32 %3, %7, %8, %9\n")
 KERNEL(k_cvt_pk_bf16_f32,"v_cvt_pk_bf16_f32 %0, %10, %11\n v_cvt_pk_bf16_f32 %1, %10, %11\n v_cvt_pk_bf16_f32 %2, %10, %11\n v_cvt_pk_bf16_f32 %3, %10, %11\n")
+KERNEL(k_lshlrev_b32, "v_lshlrev_b32 %0, 16, %6\n v_lshlrev_b32 %1, 16, %7\n v_lshlrev_b32 %2, 16, %8\n v_lshlrev_b32 %3, 16, %9\n")
+KERNEL(k_and_literal, "v_and_b32 %0, 0xffff0000, %6\n v_and_b32 %1, 0xffff0000, %7\n v_and_b32 %2, 0xffff0000, %8\n v_and_b32 %3, 0xffff0000, %9\n")
+KERNEL(k_pk_maximum3_f16, "v_pk_maximum3_f16 %0, %6, %7, %0\n v_pk_maximum3_f16 %1, %6, %8, %1\n v_pk_maximum3_f16 %2, %6, %9, %2\n v_pk_maximum3_f16 %3, %7, %8, %3\n")
+KERNEL(k_mov_b32, "v_mov_b32 %0, %6\n v_mov_b32 %1, %7\n v_mov_b32 %2, %8\n v_mov_b32 %3, %9\n")
+KERNEL(k_fma_mixlo_f16, "v_fma_mixlo_f16 %0, %10, %11, %10\n v_fma_mixlo_f16 %1, %10, %11, %11\n v_fma_mixlo_f16 %2, %11, %11, %10\n v_fma_mixlo_f16 %3, %10, %10, %11\n")
+KERNEL(k_add_u32, "v_add_u32 %0, %6, %7\n v_add_u32 %1, %6, %8\n v_add_u32 %2, %6, %9\n v_add_u32 %3, %7, %8\n")
+KERNEL(k_cvt_f32_bf16_insn, "v_cvt_f32_bf16 %0, %6\n v_cvt_f32_bf16 %1, %7\n v_cvt_f32_bf16 %2, %8\n v_cvt_f32_bf16 %3, %9\n")
+KERNEL(k_cmp_only, "v_cmp_lt_f32 vcc, %10, %11\n v_cmp_lt_f32 vcc, %11, %10\n v_cmp_lt_u32 vcc, %6, %7\n v_cmp_lt_u32 vcc, %8, %9\n")
+KERNEL(k_cndmask_only, "v_cndmask_b32 %0, %6, %7, vcc\n v_cndmask_b32 %1, %6, %8, vcc\n v_cndmask_b32 %2, %6, %9, vcc\n v_cndmask_b32 %3, %7, %8, vcc\n")
+KERNEL(k_min_f16, "v_min_f16 %0, %6, %7\n v_min_f16 %1, %6, %8\n v_min_f16 %2, %6, %9\n v_min_f16 %3, %7, %8\n")
+KERNEL(k_max_u32_dpp, "v_max_u32_dpp %0, %6, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %1, %7, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %2, %8, %2 row_mirror row_mask:0xf bank_mask:0xf\n v_max_u32_dpp %3, %9, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n")
+KERNEL(k_fmac_f32, "v_fmac_f32 %0, %10, %11\n v_fmac_f32 %1, %10, %11\n v_fmac_f32 %2, %10, %11\n v_fmac_f32 %3, %10, %11\n")
+KERNEL(k_mul_f16, "v_mul_f16 %0, %6, %7\n v_mul_f16 %1, %6, %8\n v_mul_f16 %2, %6, %9\n v_mul_f16 %3, %7, %8\n")
 KERNEL(k_salu,      "s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n")
 
 typedef void (*kfn)(uint32_t*, int);
@@ -70,11 +83,11 @@ int main() {
                 E(k_cvt_pk_f16_f32), E(k_pk_add_f16), E(k_pk_mul_f16), E(k_pk_fma_f16), E(k_pk_max_u16), E(k_pk_min_f16), E(k_and_b32),
                 E(k_bfi_b32), E(k_perm_b32), E(k_rndne_f16), E(k_fma_mix), E(k_mov_dpp), E(k_add_f64), E(k_fma_f64), E(k_cvt_f64_f32),
                 E(k_rcp_f32), E(k_cvt_i32_f32), E(k_cmp_cndmask), E(k_med3_f16), E(k_lshl_add_u64), E(k_pk_add_u16), E(k_add_f16),
-                E(k_cvt_f32_bf16), E(k_dot2_f32_f16), E(k_dot2c_f32_f16), E(k_max3_f16_abs), E(k_fma_mix_abs), E(k_add_f32_abs), E(k_pk_add_f32), E(k_max_f16), E(k_pk_max_f16), E(k_max3_u32), E(k_and_or_b32), E(k_cvt_pk_bf16_f32), E(k_salu)};
+                E(k_cvt_f32_bf16), E(k_dot2_f32_f16), E(k_dot2c_f32_f16), E(k_max3_f16_abs), E(k_fma_mix_abs), E(k_add_f32_abs), E(k_pk_add_f32), E(k_max_f16), E(k_pk_max_f16), E(k_max3_u32), E(k_and_or_b32), E(k_cvt_pk_bf16_f32), E(k_lshlrev_b32), E(k_and_literal), E(k_pk_maximum3_f16), E(k_mov_b32), E(k_fma_mixlo_f16), E(k_add_u32), E(k_cvt_f32_bf16_insn), E(k_cmp_only), E(k_cndmask_only), E(k_min_f16), E(k_max_u32_dpp), E(k_fmac_f32), E(k_mul_f16), E(k_salu)};
   uint32_t* out; hipMalloc(&out, 256 * 8 * 256 * 4 * 2);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 2000;
-  for (int occ : {8, 4, 1}) {
+  for (int occ : {4}) {
     printf("--- %d waves/SIMD (blocks/CU = %d)\n", occ, occ);
     for (auto& en : ents) {
       int grid = 256 * occ;  // 256 CUs x occ blocks of 4 waves -> occ waves per SIMD
