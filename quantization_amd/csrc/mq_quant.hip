@@ -1103,15 +1103,14 @@ __device__ __forceinline__ u32x4 stats_cvt(u32x4 raw) {
   if constexpr (BF16) return bf16x8_to_f16(raw);
   else return raw;
 }
-#ifndef MQ_STATS_NT
-#define MQ_STATS_NT 1  // weights are read once: non-temporal loads (measured 7.0 against 6.3 TB/s for a plain read)
-#endif
+// NT: non-temporal load.  The weights are read once; for whole 1 KiB runs per wave instruction (rows) a
+// non-temporal read measured 7.0 against 6.3 TB/s.  The group kernels' instructions read runs of 16 * T bytes and
+// four of them share every cache line: there the line must stay in the vector cache (plain loads; non-temporal
+// ones took g = 32 from 123 to 159 us per 16 x 4096^2).
+template <bool NT>
 __device__ __forceinline__ u32x4 stats_load(const char* ptr) {
-#if MQ_STATS_NT
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
-#else
-  return *reinterpret_cast<const u32x4*>(ptr);
-#endif
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
+  else return *reinterpret_cast<const u32x4*>(ptr);
 }
 // One lane's reduction word over NV vectors: absmax bits, or (min | max << 16).  v_pk_maximum3 / minimum3_f16 take
 // two new words per instruction and, unlike v_pk_max / min_f16, return a NaN when an operand is one (a NaN in the
@@ -1234,11 +1233,11 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     const char* sb = wb + t * 4096 + loff;
     if (t < full) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = stats_load(sb + j * (16 * T));
+      for (int j = 0; j < NV; ++j) dst[j] = stats_load<false>(sb + j * (16 * T));
     } else {  // the last, partial step
       const bool in = t * SPW + team < p.nseg;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = in ? stats_load(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
+      for (int j = 0; j < NV; ++j) dst[j] = in ? stats_load<false>(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
     }
   };
   auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take) __attribute__((always_inline)) {
@@ -1327,11 +1326,11 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const Quan
     const char* sb = wb + row * row_bytes + loff;
     if (whole) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = stats_load(sb + j * (1024 * WPR));
+      for (int j = 0; j < NV; ++j) dst[j] = stats_load<true>(sb + j * (1024 * WPR));
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j)
-        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? stats_load(sb + j * (1024 * WPR)) : u32x4{0, 0, 0, 0};
+        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? stats_load<true>(sb + j * (1024 * WPR)) : u32x4{0, 0, 0, 0};
     }
   };
   // this row's parameters from the lane's vectors (every wave of the row gets the same)

@@ -7,6 +7,36 @@
 #include <cstdio>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// the same read with a small store per 4 KiB step: SB bytes per lane from the first LANES lanes (8 x 64: the
+// float64 per-group sums of g = 32; 8 x 16: g = 128; 4 x 64: float32 sums of g = 32)
+template <int SB, int LANES, bool NTS>
+__global__ __launch_bounds__(256) void k_read_store(const u32x4* __restrict__ w, char* __restrict__ st, int64_t nvec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  const int64_t tiles = nvec / 256;
+  u32x4 nxt[4];
+  if (gw < tiles)
+    for (int j = 0; j < 4; ++j) nxt[j] = __builtin_nontemporal_load(&w[(gw * 4 + j) * 64 + lane]);
+  for (int64_t t = gw; t < tiles; t += nw) {
+    u32x4 raw[4];
+    for (int j = 0; j < 4; ++j) raw[j] = nxt[j];
+    if (t + nw < tiles)
+      for (int j = 0; j < 4; ++j) nxt[j] = __builtin_nontemporal_load(&w[((t + nw) * 4 + j) * 64 + lane]);
+    uint32_t a = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a ^= raw[j][0] ^ raw[j][1] ^ raw[j][2] ^ raw[j][3];
+    if (lane < LANES) {
+      char* dst = st + (t * LANES + lane) * SB;
+      if constexpr (SB == 8) {
+        uint64_t v = ((uint64_t)a << 32) | a;
+        if (NTS) __builtin_nontemporal_store(v, (uint64_t*)dst); else *(uint64_t*)dst = v;
+      } else {
+        if (NTS) __builtin_nontemporal_store(a, (uint32_t*)dst); else *(uint32_t*)dst = a;
+      }
+    }
+  }
+}
+
 template <int NV, int WORK, bool NT, bool RUN64>
 __global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ w, uint32_t* __restrict__ out, int64_t nvec) {
   const int lane = threadIdx.x & 63;
@@ -57,7 +87,28 @@ int main() {
     }
     printf("%-34s grid %5d  %7.1f us  %6.2f TB/s\n", name, grid, best * 1e3, bytes / best / 1e9);
   };
-  for (int grid : {1024, 2048, 4096, 8192, 16384, 32768}) {
+  {
+    void* st; hipMalloc(&st, n / 4);
+    auto run2 = [&](const char* name, auto kern, int grid) {
+      float best = 1e9;
+      for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const u32x4*)w, (char*)st, nvec);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+      }
+      printf("%-44s grid %5d  %7.1f us  %6.2f TB/s of reads\n", name, grid, best * 1e3, bytes / best / 1e9);
+    };
+    for (int grid : {4096, 8192}) {
+      run2("read + 8 B x 64 lanes per 4 KiB", k_read_store<8, 64, false>, grid);
+      run2("read + 8 B x 64 lanes per 4 KiB, nt store", k_read_store<8, 64, true>, grid);
+      run2("read + 4 B x 64 lanes per 4 KiB", k_read_store<4, 64, false>, grid);
+      run2("read + 8 B x 16 lanes per 4 KiB", k_read_store<8, 16, false>, grid);
+      run2("read + 4 B x 16 lanes per 4 KiB", k_read_store<4, 16, false>, grid);
+      run2("read + 8 B x 1 lane per 4 KiB", k_read_store<8, 1, false>, grid);
+    }
+  }
+  for (int grid : {8192}) {
     run("NV4 contiguous", k_read<4, 0, false, false>, grid);
     run("NV4 contiguous nt", k_read<4, 0, true, false>, grid);
     run("NV8 contiguous", k_read<8, 0, false, false>, grid);
