@@ -158,15 +158,15 @@ MQ_PK_OP(pk_min_u16, "v_pk_min_u16")
 MQ_PK_OP(pk_max_u16, "v_pk_max_u16")
 MQ_PK_OP(pk_add_u16, "v_pk_add_u16")
 MQ_PK_OP(pk_sub_u16, "v_pk_sub_u16")
+// NaN-propagating packed float16 max / min of three (gfx950): a NaN operand gives a NaN half, -0 < +0
+MQ_PK_OP3(pk_maximum3_f16, "v_pk_maximum3_f16")
+MQ_PK_OP3(pk_minimum3_f16, "v_pk_minimum3_f16")
 __device__ __forceinline__ uint32_t pk_sub_u16_sat(uint32_t a, uint32_t b) {
   uint32_t r;
   asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
 __device__ __forceinline__ uint32_t pk_shr_u16(uint32_t sh, uint32_t v);
-// NaN-propagating packed float16 max / min of three (gfx950): a NaN operand gives a NaN half, -0 < +0
-MQ_PK_OP3(pk_maximum3_f16, "v_pk_maximum3_f16")
-MQ_PK_OP3(pk_minimum3_f16, "v_pk_minimum3_f16")
 __device__ __forceinline__ h16x2 as_h2(uint32_t w) { return __builtin_bit_cast(h16x2, w); }
 __device__ __forceinline__ uint32_t as_u32(h16x2 h) { return __builtin_bit_cast(uint32_t, h); }
 __device__ __forceinline__ uint32_t dup16(uint32_t b) { return (b & 0xffffu) | (b << 16); }
@@ -277,20 +277,22 @@ __device__ __forceinline__ uint32_t fold_max_u16(uint32_t pk) {
   uint32_t a = pk & 0xffffu, b = pk >> 16;
   return a > b ? a : b;
 }
-// packed (min over even, min over odd) / (max ...) of the signed float16 values
+// packed (min over even, min over odd) / (max ...) of the signed float16 values.  v_pk_minimum3 / maximum3_f16
+// (gfx950) return a NaN when an operand is one -- torch.amin / amax propagate a NaN in the segment into scale and
+// zero-point, and v_pk_min / max_f16 would drop it.
 __device__ __forceinline__ void minmax8_pk(u32x4 v, uint32_t& lo, uint32_t& hi) {
-  lo = pk_min_f16(pk_min_f16(v[0], v[1]), pk_min_f16(v[2], v[3]));
-  hi = pk_max_f16(pk_max_f16(v[0], v[1]), pk_max_f16(v[2], v[3]));
+  lo = pk_minimum3_f16(pk_minimum3_f16(v[0], v[1], v[2]), v[3], v[3]);
+  hi = pk_maximum3_f16(pk_maximum3_f16(v[0], v[1], v[2]), v[3], v[3]);
 }
 // -> one word: min in the low half, max in the high half
 __device__ __forceinline__ uint32_t fold_minmax(uint32_t lo, uint32_t hi) {
   // (lo.l, hi.l) vs (lo.h, hi.h): min of the low halves, max of the high halves
   uint32_t a = (lo & 0xffffu) | (hi << 16), b = (lo >> 16) | (hi & 0xffff0000u);
-  uint32_t mn = pk_min_f16(a, b), mx = pk_max_f16(a, b);
+  uint32_t mn = pk_minimum3_f16(a, b, b), mx = pk_maximum3_f16(a, b, b);
   return (mn & 0xffffu) | (mx & 0xffff0000u);
 }
 __device__ __forceinline__ uint32_t op_minmax(uint32_t a, uint32_t b) {
-  uint32_t mn = pk_min_f16(a, b), mx = pk_max_f16(a, b);
+  uint32_t mn = pk_minimum3_f16(a, b, b), mx = pk_maximum3_f16(a, b, b);
   return (mn & 0xffffu) | (mx & 0xffff0000u);
 }
 __device__ __forceinline__ uint32_t op_max_u32(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -511,7 +513,8 @@ __device__ __forceinline__ void error_sums(const float* e, double& sse, double& 
 //  * the float16 operands of the exact division go into v_fma_mix_f32 as they are (no float16 -> float32
 //    conversions): q0 = v * r, rem = fma(-q0, s, v), q1 = fma(rem, r, q0), the same three roundings as div_f;
 //  * e = v - d is taken in packed float16.  It is EXACT there: on this path d is 0 or within a factor 2 of v
-//    (Sterbenz), checked for every (scale, value) pair the fast path admits by tests/tools/sterbenz_exhaustive.c;
+//    (Sterbenz), checked for every (scale, value) pair the fast path admits by tests/tools/sterbenz_exhaustive.c
+//    (tables without subnormals are the exception and take the float32 difference, see quant8_stats);
 //  * sum e^2 and sum |e| go through v_dot2_f32_f16 (float16 products are exact in float32; float16 subnormals are
 //    honoured; the two-term sum is not single-rounded, about one float32 ulp per step, far inside the 1e-6 bar).
 __device__ __forceinline__ float mix_mul_lo(uint32_t vw, float r) {
@@ -566,7 +569,7 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
                                              float& sabs) {
   const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
-  float q = 0.f;
+  float q = 0.f, q1 = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t vw = raw[k];
@@ -582,15 +585,26 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
       uint32_t t = pk_min_f16(pk_max_f16(as_u32(x + magic), as_u32(lo)), as_u32(hi));
       e = as_h2(vw) - (as_h2(t) - magic) * s2;
     } else if constexpr (FMT == MQ_LUT_FP) {
-      // magnitudes: |e| = | |v| - |q| s |, the table value has the sign of v or is zero
-      const uint32_t qm = lut_round_mag_pk(as_u32(x), vw, p.lut);
-      e = as_h2(vw & 0x7fff7fffu) - as_h2(qm) * s2;
+      // magnitudes: |e| = | |v| - |q| s |, the table value has the sign of v or is zero.  Here the error is
+      // taken in float32: a negative x exactly on the midpoint between 0 and the smallest entry goes to that
+      // entry (ties toward -inf), d is then 2 |v| (1 + 2^-11) and v - d needs 12 bits (13 float16 patterns per
+      // scale binade for fp8_e4m3: tests/tools/sterbenz_exhaustive.c).  Plain float32 instructions issue at
+      // 2.4 .. 2.6 cycles, so this costs ~3 cycles per pair more than the packed form.
+      const uint32_t dm = as_u32(as_h2(lut_round_mag_pk(as_u32(x), vw, p.lut)) * s2);
+      float e0, e1;
+      asm("v_fma_mix_f32 %0, -%1, 1.0, |%2| op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(e0) : "v"(dm), "v"(vw));
+      asm("v_fma_mix_f32 %0, -%1, 1.0, |%2| op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(e1) : "v"(dm), "v"(vw));
+      q = __builtin_fmaf(e0, e0, q);    // two chains of 4 steps per vector, as the dot form has
+      q1 = __builtin_fmaf(e1, e1, q1);
+      sabs += __builtin_fabsf(e0) + __builtin_fabsf(e1);
+      continue;
     } else {
       e = as_h2(vw) - as_h2(lut_round_pk_sub(as_u32(x), p.lut)) * s2;
     }
     q = __builtin_amdgcn_fdot2(e, e, q, false);
     sabs = __builtin_amdgcn_fdot2(as_h2(as_u32(e) & 0x7fff7fffu), as_h2(0x3c003c00u), sabs, false);
   }
+  if constexpr (FMT == MQ_LUT_FP) q += q1;
   sse += q;
 }
 
@@ -1134,12 +1148,9 @@ __device__ __forceinline__ uint32_t stats_lane_reduce(const u32x4* raw) {
     return fold_max_u16(pk_max_u16(mx & 0x7fff7fffu, mn & 0x7fff7fffu));  // integer max: a NaN wins
   }
 }
-__device__ __forceinline__ uint32_t op_minmax_nan(uint32_t a, uint32_t b) {
-  return (pk_minimum3_f16(a, b, b) & 0xffffu) | (pk_maximum3_f16(a, b, b) & 0xffff0000u);
-}
 template <int FMT>
 __device__ __forceinline__ uint32_t stats_op(uint32_t a, uint32_t b) {
-  if constexpr (FMT == MQ_INT_ASYM) return op_minmax_nan(a, b);
+  if constexpr (FMT == MQ_INT_ASYM) return op_minmax(a, b);
   else return op_max_u32(a, b);
 }
 // params_absmax / params_minmax with the common case in few instructions: h(a / qmax) by the reciprocal multiply
@@ -1342,7 +1353,7 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const Quan
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           u32x4 one[1] = {raw[j]};
-          if ((j * WPR + sub) * 64 + lane < p.vecs_per_seg) red = op_minmax_nan(red, stats_lane_reduce<FMT, 1>(one));
+          if ((j * WPR + sub) * 64 + lane < p.vecs_per_seg) red = op_minmax(red, stats_lane_reduce<FMT, 1>(one));
         }
       }
     }

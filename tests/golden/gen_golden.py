@@ -19,6 +19,8 @@ Files written:
                         (_fp_quant_meta + quant_datatype), fp8_e5m2 (float32 results) and quant_mx; small inputs,
                         non-finite inputs, and all float16 patterns for a subset
   quant_search.npz      search_datatype (mixed_bitmod / mixed_er / mixed_ea / mixed_ant, 3 and 4 bits) on float16 inputs
+  quant_specials.npz    the four headline formats on rows holding +-inf / NaN, rows on one side of zero, all-zero
+                        and constant rows, values at the float16 limits (per-channel, g=64, per-tensor)
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
@@ -287,6 +289,35 @@ def gen_more_formats():
     print("quant_more_formats.npz", len(arrays), "arrays")
 
 
+def gen_specials():
+    """Non-finite and one-sided rows through the reference's int8 / int8_asym / fp8 paths (the other fixture files
+    hold them only for the explicit-list formats)."""
+    gen = torch.Generator().manual_seed(21)
+    w = torch.randn(16, 512, generator=gen) * 0.02
+    w[0, 3], w[0, 7] = float("inf"), float("-inf")
+    w[1, 5] = float("-inf")
+    w[2, 9] = float("nan")
+    w[3, 100] = float("inf")
+    w[4] = w[4].abs() + 0.01          # all positive
+    w[5] = -w[5].abs() - 0.01         # all negative
+    w[6] = 0                          # all zero
+    w[7] = 0.0123                     # constant
+    w[8, :64] = w[8, :64].abs()       # one group on one side of zero
+    w[9, 64:128] = -w[9, 64:128].abs() - 1.0
+    w[10, 17] = 65504.0               # float16 maximum
+    w[11, 17] = -65504.0
+    w[12] = w[12] * 1e-4              # subnormal-sized values
+    w[13, 40] = float("nan")
+    w[13, 300] = float("inf")
+    arrays = {"in": bits16(w.half())}
+    for fmt in FORMATS:
+        for gs in [None, 64, -1]:
+            for k, v in run_reference(w.half(), fmt, gs).items():
+                arrays[f"out/{fmt}/{gs_key(gs)}/{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "quant_specials.npz"), **arrays)
+    print("quant_specials.npz", len(arrays), "arrays")
+
+
 MIXED = ["mixed_bitmod", "mixed_er", "mixed_ea", "mixed_ant"]
 
 
@@ -379,6 +410,9 @@ if __name__ == "__main__":
         gen_lut_tables()
         gen_more_formats()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "specials":
+        gen_specials()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "search":
         gen_search()
         sys.exit(0)
@@ -390,6 +424,7 @@ if __name__ == "__main__":
     gen_more_formats()
     gen_table_formats()
     gen_search()
+    gen_specials()
     gen_quant_small()
     gen_exhaustive()
     gen_lut_domain()

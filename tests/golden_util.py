@@ -43,6 +43,21 @@ def exhaustive_expected(fmt, gs):
     return z["in"], {k[len(pre):]: z[k] for k in z if k.startswith(pre)}
 
 
+def specials_expected(fmt, gs):
+    """quant_specials.npz: rows with +-inf / NaN, one-sided rows, constant rows, float16 limits."""
+    z = npz("quant_specials.npz")
+    pre = f"out/{fmt}/{gs_key(gs)}/"
+    return z["in"], {k[len(pre):]: z[k] for k in z if k.startswith(pre)}
+
+
+def same_f16_bits(got, exp):
+    """Bit equality of two float16 bit arrays where every NaN equals every NaN (payloads and signs of NaNs are
+    whatever the producing instruction leaves)."""
+    got, exp = np.asarray(got).reshape(-1), np.asarray(exp).reshape(-1)
+    gn, en = (got & 0x7fff) > 0x7c00, (exp & 0x7fff) > 0x7c00
+    return bool(np.array_equal(gn, en) and np.array_equal(got[~gn], exp[~en]))
+
+
 # formats beyond the 8-bit headline set (quant_more_formats.npz): (wq_bits, table name)
 MORE_TABLES = [(4, "fp4"), (5, "fp5_e2m2"), (5, "fp5_e3m1"), (6, "fp6_e2m3"), (6, "fp6_e3m2"), (8, "fp8_e2m5"),
                (3, "int3"), (4, "int4"), (6, "int6")]

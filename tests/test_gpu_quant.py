@@ -89,6 +89,24 @@ def test_golden_exhaustive(qa, fmt, gs):
     assert_same(run_api(qa, to_dev(arr, "f16"), fmt, gs), exp, f"exhaustive/{fmt}/{gs}")
 
 
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", [None, 64, -1], ids=gu.gs_key)
+def test_golden_special_rows(qa, fmt, gs):
+    """Rows with +-inf / NaN, rows on one side of zero, constant rows, float16 limits, as the reference leaves
+    them (NaN == NaN; codes compared wherever the dequantized value is a number)."""
+    arr, exp = gu.specials_expected(fmt, gs)
+    got = run_api(qa, to_dev(arr, "f16"), fmt, gs)
+    for k in ("deq", "scale", "zp", "deq_quant_datatype"):
+        if k in exp:
+            assert gu.same_f16_bits(got[k], exp[k]), f"{fmt}/{gs}: {k}"
+    ok = (exp["deq"].reshape(-1) & 0x7fff) <= 0x7c00
+    if fmt.startswith("int"):
+        assert np.array_equal(got["q"].reshape(-1)[ok], exp["q"].reshape(-1)[ok]), f"{fmt}/{gs}: codes"
+        assert bool(exp["q_is_int8"]) == got["q_is_int8"]
+    else:
+        assert gu.same_f16_bits(got["q"].reshape(-1)[ok], exp["q"].reshape(-1)[ok]), f"{fmt}/{gs}: codes"
+
+
 @pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp8_e3m4"])
 def test_golden_lut_domain(qa, fmt):
     z = gu.npz("lut_domain.npz")

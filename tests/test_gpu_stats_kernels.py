@@ -1,0 +1,135 @@
+"""GPU: the statistics-only kernels of the model sweeps (k_stats_group / k_stats_row: no element-sized output)
+against the CPU oracle, on every kernel variant and on rows the fast path must hand to the per-element path.
+
+Scales and zero-points: the oracle's bits (NaN == NaN).  Per-segment and per-tensor sums of squared errors and the
+sum of absolute errors: within 1e-6 relative of the float64 sums of the oracle's float32 errors
+(quant_error_multi_weight.py:55-58 squares in float32; the kernels add a lane's exact float32 squares with
+v_dot2_f32_f16 and carry everything above two vectors in float64).  A non-finite expected sum must be non-finite
+of the same kind."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+# (rows, cols, group size): every template instance the launcher can pick
+#   groups of 32 * T elements, T = 1 .. 16 lanes per group, with a last partial wave step
+#   rows held by one wave, 2 / 4 / 8 / 12 / 16 vectors per lane, whole and ragged
+#   rows held by a 256-thread workgroup, 7 / 8 / 14 / 16 vectors per lane, whole and ragged
+SHAPES = [
+    (37, 1024, 32), (19, 1024, 64), (21, 2048, 128), (13, 2048, 256), (9, 2048, 512), (3, 96, 32),
+    (11, 1024, None), (9, 1000, None), (7, 2048, None), (5, 4096, None), (5, 3000, None), (3, 5632, None),
+    (3, 8192, None), (3, 7000, None),
+    (3, 14336, None), (2, 16384, None), (2, 15000, None), (2, 28672, None), (2, 32768, None), (2, 30000, None),
+]
+FORMATS = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("int2", 2), ("fp8_e4m3", 8), ("fp8_e3m4", 8), ("fp4", 4)]
+
+
+def _inputs(rows, cols, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(rows, cols, generator=g) * 0.02
+    w[0, 3] = 0.5                                   # an outlier
+    if rows > 2:
+        w[2] = 0                                    # a zero row
+    if rows > 4:
+        w[3] = w[3].abs() + 0.003                   # a row on one side of zero (asymmetric: per-element path)
+        w[4, : cols // 2] = -w[4, : cols // 2].abs()
+    if rows > 6:
+        w[5, 7] = float("inf")
+        w[6, cols - 1] = float("nan")
+    if rows > 8:
+        w[7] = w[7] * 1e-4                          # float16 subnormals
+        w[8, 1] = 65504.0                           # the scale of tiny bit widths reaches the upper clamp
+    return w
+
+
+def _fmt(orc, lib, name, bits):
+    if name.startswith("int"):
+        asym = "asym" in name
+        return (lib.INT_ASYM if asym else lib.INT_SYM, None), dict(fmt=orc.INT_ASYM if asym else orc.INT_SYM, bits=bits)
+    return (lib.LUT_FP, name), dict(fmt=orc.LUT, bits=bits, datatype=name)
+
+
+def _close(got, want, what):
+    got, want = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(want, dtype=np.float64).reshape(-1)
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern"
+    assert np.array_equal(np.isinf(got), np.isinf(want)), f"{what}: inf pattern"
+    err = np.abs(got[fin] - want[fin])
+    bad = err > 1e-6 * np.abs(want[fin])
+    assert not bad.any(), f"{what}: {bad.sum()} of {fin.sum()} beyond 1e-6, worst {np.max(err / np.maximum(np.abs(want[fin]), 1e-300))}"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("fmt", FORMATS, ids=[f[0] for f in FORMATS])
+def test_statistics_kernels_vs_oracle(oracle, fmt, dt):
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    name, bits = fmt
+    for k, (rows, cols, gs) in enumerate(SHAPES):
+        w = _inputs(rows, cols, 100 + k)
+        wt = w.half() if dt == "f16" else w.bfloat16()
+        (code, table), oargs = _fmt(oracle, _lib, name, bits)
+        res = quantize(wt.cuda(), code, bits, gs, table, deq=False, codes=False, scale=True, seg_sse=True, totals=True)
+        raw = wt.view(torch.int16).numpy().view(np.uint16)
+        exp = oracle.quantize(raw, oracle.F16 if dt == "f16" else oracle.BF16, group_size=gs, **oargs)
+        what = f"{name}/{dt}/{rows}x{cols}/g={gs}"
+        assert gu.same_f16_bits(res.scale.view(torch.int16).cpu().numpy().view(np.uint16), exp["scale"]), what + " scale"
+        if "asym" in name:
+            assert gu.same_f16_bits(res.zero_point.view(torch.int16).cpu().numpy().view(np.uint16), exp["zp"]), what + " zp"
+        v = wt.half().float().numpy()                       # the reference measures against float16(w)
+        with np.errstate(invalid="ignore", over="ignore"):
+            e = v - exp["deq"].view(np.float16).astype(np.float32).reshape(rows, cols)
+            sq = (e * e).astype(np.float32).astype(np.float64)
+            L = cols if gs is None else gs
+            _close(res.seg_sse.cpu().numpy(), sq.reshape(-1, L).sum(axis=1), what + " seg_sse")
+            tot = res.totals.cpu().numpy()
+            _close(tot[0], sq.sum(), what + " sse")
+            _close(tot[1], np.abs(e).astype(np.float64).sum(), what + " sum|err|")
+
+
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", [None, 64], ids=gu.gs_key)
+def test_statistics_kernels_special_rows_golden(fmt, gs):
+    """Scales / zero-points of the statistics kernels on the reference-generated rows with +-inf / NaN, rows on
+    one side of zero, constant rows and float16 limits (tests/golden/quant_specials.npz)."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    w, exp = gu.specials_expected(fmt, gs)
+    wt = torch.from_numpy(w.view(np.int16).copy()).view(torch.float16).cuda()
+    code = {"int8": _lib.INT_SYM, "int8_asym": _lib.INT_ASYM}.get(fmt, _lib.LUT_FP)
+    res = quantize(wt, code, 8, gs, fmt if code == _lib.LUT_FP else None, deq=False, codes=False, scale=True,
+                   seg_sse=True, totals=True)
+    assert gu.same_f16_bits(res.scale.view(torch.int16).cpu().numpy().view(np.uint16), exp["scale"]), "scale"
+    if "zp" in exp:
+        assert gu.same_f16_bits(res.zero_point.view(torch.int16).cpu().numpy().view(np.uint16), exp["zp"]), "zp"
+    with np.errstate(invalid="ignore", over="ignore"):
+        e = w.view(np.float16).astype(np.float32) - exp["deq"].view(np.float16).astype(np.float32).reshape(w.shape)
+        sq = (e * e).astype(np.float32).astype(np.float64)
+        _close(res.seg_sse.cpu().numpy(), sq.reshape(-1, w.shape[1] if gs is None else gs).sum(axis=1), "seg_sse")
+
+
+def test_float16_error_is_exact_on_every_pattern():
+    """The statistics kernels take v - d in float16 (exact by Sterbenz on the fast path: the CPU proof is
+    tests/tools/sterbenz_exhaustive.c).  The general kernels expose both forms of the same error -- |f32(v) -
+    f32(d)| and the float16-arithmetic |h(v - d)| -- so on the matrix of all float16 bit patterns the two dumps
+    must agree bit for bit wherever the segment is finite."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    w, _ = gu.exhaustive_expected("int8", None)
+    wt = torch.from_numpy(w.view(np.int16).copy()).view(torch.float16).cuda()
+    for code, table, bits in [(_lib.INT_SYM, None, 8), (_lib.INT_ASYM, None, 8), (_lib.INT_SYM, None, 4),
+                              (_lib.LUT_FP, "fp8_e3m4", 8), (_lib.LUT_FP, "fp4", 4)]:
+        for gs in (None, 128, 32):
+            a = quantize(wt, code, bits, gs, table, deq=False, codes=False, scale=False, abs_err=torch.float32)
+            b = quantize(wt, code, bits, gs, table, deq=False, codes=False, scale=False, abs_err=torch.float16)
+            if code == _lib.INT_ASYM:
+                # rows of one sign are off the fast path (their clamped codes may lie far from v): leave them out
+                L = wt.shape[1] if gs is None else gs
+                seg = wt.float().reshape(-1, L)
+                keep = ((seg.min(dim=1).values <= 0) & (seg.max(dim=1).values >= 0)).repeat_interleave(L).reshape(wt.shape)
+            else:
+                keep = torch.ones_like(wt, dtype=torch.bool)
+            assert torch.equal(a.abs_err[keep], b.abs_err[keep].float()), (code, table, bits, gs)

@@ -47,6 +47,26 @@ def test_exhaustive_f16_patterns(oracle, fmt, gs):
     _check(oracle, w, "f16", fmt, gs, exp)
 
 
+@pytest.mark.parametrize("fmt", gu.FORMATS)
+@pytest.mark.parametrize("gs", [None, 64, -1], ids=gu.gs_key)
+def test_special_rows(oracle, fmt, gs):
+    """+-inf / NaN rows, rows on one side of zero, constant rows, float16 limits: dequantized values, scales and
+    zero-points as the reference leaves them (NaN == NaN); codes wherever the dequantized value is a number (the
+    integer a NaN code becomes is the host's float -> int cast, not arithmetic)."""
+    w, exp = gu.specials_expected(fmt, gs)
+    K, C = w.shape
+    out = oracle.quantize(w, oracle.F16, group_size=gs, **_fmt_args(oracle, fmt))
+    assert gu.same_f16_bits(out["deq"], exp["deq"]), "deq"
+    assert gu.same_f16_bits(out["scale"], exp["scale"]), "scale"
+    if "zp" in exp:
+        assert gu.same_f16_bits(out["zp"], exp["zp"]), "zero-point"
+    ok = (exp["deq"].reshape(-1) & 0x7fff) <= 0x7c00
+    if fmt.startswith("int"):
+        assert np.array_equal(out["q"].reshape(-1)[ok], exp["q"].reshape(-1)[ok]), "codes"
+    else:
+        assert gu.same_f16_bits(out["q"].reshape(-1)[ok], exp["q"].reshape(-1)[ok]), "codes"
+
+
 @pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp8_e3m4"])
 def test_lut_domain_sweep(oracle, fmt):
     """Every float16 x with |x| <= LUTmax through the reference's LUT rounding (scale == 1)."""
