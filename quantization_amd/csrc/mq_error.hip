@@ -158,6 +158,19 @@ __global__ __launch_bounds__(256) void k_err_cols(ErrParams p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) p.col_part[rc * p.cols + cv * 8 + i] = acc[i];
 }
+// The same for any column count / alignment: thread (c, rc) owns one column (consecutive lanes read consecutive
+// elements of a row).
+__global__ __launch_bounds__(256) void k_err_cols_scalar(ErrParams p) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.cols * p.row_chunks) return;
+  const int64_t c = t % p.cols, rc = t / p.cols;
+  double acc = 0.0;
+  for (int64_t r = rc; r < p.rows; r += p.row_chunks) {
+    const float e = load1(p.a, p.dtype, r * p.cols + c) - load1(p.b, p.dtype, r * p.cols + c);
+    acc += (double)(e * e);
+  }
+  p.col_part[rc * p.cols + c] = acc;
+}
 // col_sse[c] = sum over chunks; block_sse[g] = sum over the block's columns (column-block form)
 __global__ __launch_bounds__(256) void k_err_cols_finish(const double* part, int row_chunks, int64_t cols,
                                                          double* col_sse) {
@@ -174,6 +187,18 @@ __global__ __launch_bounds__(256) void k_err_generic(ErrParams p) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int64_t L = p.seg_len ? p.seg_len : p.n, nseg = p.n / L;
   double acc_sq = 0.0, acc_ab = 0.0;
+  if (!p.seg_sse) {  // totals / dump only: every workgroup takes its share of the flat tensor
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+      float x = load1(p.a, p.dtype, i), y = load1(p.b, p.dtype, i);
+      float e = x - y, ab = __builtin_fabsf(e);
+      if (p.abs_err_mode == 1) static_cast<float*>(p.abs_err)[i] = ab;
+      else if (p.abs_err_mode == 2) static_cast<uint16_t*>(p.abs_err)[i] = (uint16_t)(f2h_bits(e) & 0x7fffu);
+      acc_sq += (double)(e * e);
+      acc_ab += (double)ab;
+    }
+    err_block_partials(p, acc_sq, acc_ab);
+    return;
+  }
   for (int64_t seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     double s = 0.0;
     for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
@@ -349,10 +374,10 @@ extern "C" size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t w
   return b;
 }
 
-extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols,
-                              int64_t seg_len, void* abs_err, int32_t abs_err_dtype, double* seg_sse,
-                              double* col_sse, double* totals, void* workspace, size_t workspace_bytes,
-                              void* hip_stream) {
+static int error_stats_impl(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,
+                            void* abs_err, int32_t abs_err_dtype, double* seg_sse, double* col_sse, double* totals,
+                            void* workspace, size_t workspace_bytes, hipStream_t st) {
+  // every argument is checked before anything is enqueued
   if (rows < 0 || cols < 0 || seg_len < 0) return MQ_ERR_ARG;
   if (dtype != MQ_F16 && dtype != MQ_F32) return MQ_ERR_ARG;
   if (abs_err && abs_err_dtype != MQ_F32 && abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
@@ -362,7 +387,11 @@ extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64
   if (n == 0) return MQ_OK;
   if (!a || !b) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < mq_error_workspace_bytes(rows, cols, col_sse != nullptr)) return MQ_ERR_WORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  const size_t esz = dtype == MQ_F32 ? 4 : 2;
+  auto al = [](const void* q, size_t k) { return (reinterpret_cast<uintptr_t>(q) % k) == 0; };
+  if (!al(a, esz) || !al(b, esz) || !al(abs_err, abs_err_dtype == MQ_F32 ? 4 : 2) || !al(seg_sse, 8) || !al(col_sse, 8) ||
+      !al(totals, 8) || !al(workspace, 8))
+    return MQ_ERR_ALIGN;
   ErrParams p = {};
   p.a = a; p.b = b; p.dtype = dtype; p.rows = rows; p.cols = cols; p.n = n;
   p.seg_len = seg_sse ? seg_len : 0;
@@ -370,9 +399,8 @@ extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64
   p.abs_err_mode = !abs_err ? 0 : (abs_err_dtype == MQ_F32 ? 1 : 2);
   p.seg_sse = seg_sse;
   p.partials = static_cast<double*>(workspace);
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
   const int64_t L = p.seg_len ? p.seg_len : n;
-  const bool vec_ok = L % 8 == 0 && n % 8 == 0 && al16(a) && al16(b) && al16(abs_err);
+  const bool vec_ok = L % 8 == 0 && n % 8 == 0 && al(a, 16) && al(b, 16) && al(abs_err, 16);
   unsigned grid;
   if (vec_ok) {
     int64_t waves;
@@ -389,28 +417,46 @@ extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64
     grid = (unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
     hipLaunchKernelGGL(k_err_rows, dim3(grid), dim3(256), 0, st, p);
   } else {
-    int64_t blocks = n / L;
-    grid = (unsigned)(blocks < 1 ? 1 : (blocks > kErrMaxGrid ? kErrMaxGrid : blocks));
+    // one workgroup per segment, or -- without segments -- a flat sweep by enough workgroups to fill the chip
+    int64_t blocks = p.seg_sse ? n / L : (n + 255) / 256;
+    const int64_t cap = p.seg_sse ? kErrMaxGrid : 2048;
+    grid = (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
     hipLaunchKernelGGL(k_err_generic, dim3(grid), dim3(256), 0, st, p);
   }
   MQ_HIP(hipGetLastError());
   if (totals) hipLaunchKernelGGL(k_err_finalize, dim3(1), dim3(256), 0, st, p.partials, (int)grid, totals);
   if (col_sse) {
-    if (cols % 8 || !al16(a) || !al16(b)) return MQ_ERR_UNSUPPORTED;
-    // enough (column-vector, row-chunk) threads to fill the chip, at most 64 chunks
-    int64_t cvecs = cols / 8;
-    int64_t chunks = (256 * 8 * 256 + cvecs - 1) / cvecs;
-    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
-    if (chunks > rows) chunks = rows;
-    p.row_chunks = (int32_t)chunks;
     p.col_part = static_cast<double*>(workspace) + (size_t)kErrMaxGrid * 2;
-    int64_t threads = cvecs * chunks;
-    hipLaunchKernelGGL(k_err_cols, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    if (cols % 8 == 0 && al(a, 16) && al(b, 16)) {
+      // enough (column-vector, row-chunk) threads to fill the chip, at most 64 chunks
+      int64_t cvecs = cols / 8;
+      int64_t chunks = (256 * 8 * 256 + cvecs - 1) / cvecs;
+      chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+      if (chunks > rows) chunks = rows;
+      p.row_chunks = (int32_t)chunks;
+      int64_t threads = cvecs * chunks;
+      hipLaunchKernelGGL(k_err_cols, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    } else {  // any column count or alignment: one column per thread
+      int64_t chunks = (256 * 8 * 256 + cols - 1) / cols;
+      chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+      if (chunks > rows) chunks = rows;
+      p.row_chunks = (int32_t)chunks;
+      int64_t threads = cols * chunks;
+      hipLaunchKernelGGL(k_err_cols_scalar, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+    }
     hipLaunchKernelGGL(k_err_cols_finish, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, p.col_part,
-                       (int)chunks, cols, col_sse);
+                       (int)p.row_chunks, cols, col_sse);
   }
   MQ_HIP(hipGetLastError());
   return MQ_OK;
+}
+
+extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols,
+                              int64_t seg_len, void* abs_err, int32_t abs_err_dtype, double* seg_sse,
+                              double* col_sse, double* totals, void* workspace, size_t workspace_bytes,
+                              void* hip_stream) {
+  return error_stats_impl(a, b, dtype, rows, cols, seg_len, abs_err, abs_err_dtype, seg_sse, col_sse, totals, workspace,
+                          workspace_bytes, static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int mq_bucketize_f16(const void* abs_err_f16, int64_t n, const double* bins_host, int32_t nbins,

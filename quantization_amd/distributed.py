@@ -95,6 +95,7 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
         raise ValueError("float32 or float64 tensors expected")
     code = _lib.F32 if dtype == torch.float32 else 3
     xs = [t.contiguous().reshape(-1) for t in tensors if t.numel()]
+    xs = [x.clone() if x.data_ptr() % 16 else x for x in xs]   # (sliced views: the kernels read 16-byte vectors)
     n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
     if dist_on:
         dist.all_reduce(n, group=group)

@@ -56,16 +56,20 @@ def _ptr(t):
 
 
 @torch.no_grad()
-def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False):
+def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False, nan_check: bool = True):
     """np.percentile(x, pct) (method 'linear') of a non-negative float32 / float64 device tensor, exact:
     two-pass (float32) or four-pass (float64) radix select on the bit patterns.  Returns a 0-d device
-    tensor of x's dtype (and the two interpolated order statistics when return_pair)."""
+    tensor of x's dtype (and the two interpolated order statistics when return_pair).  nan_check: one more pass
+    over x that turns the result into NaN when x holds one, as numpy does (without it a NaN counts as the
+    largest value)."""
     x = require_device(x)
     if x.dtype not in (torch.float32, torch.float64):
         raise ValueError("percentile() takes float32 or float64")
     x = x.contiguous().reshape(-1)
     if x.numel() == 0:
         raise IndexError("percentile of an empty array")
+    if x.data_ptr() % 16:
+        x = x.clone()   # (a sliced view: the kernels read 16-byte vectors)
     L = _bind()
     out = torch.empty((), dtype=x.dtype, device=x.device)
     pair = torch.empty(2, dtype=x.dtype, device=x.device) if return_pair else None
@@ -74,6 +78,9 @@ def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False):
         st = L.mq_percentile(x.data_ptr(), _DT[x.dtype], x.numel(), float(pct), out.data_ptr(), _ptr(pair),
                              ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
+    if nan_check:
+        # the select orders a NaN above every number; np.percentile returns NaN when the array holds one
+        out = torch.where(torch.isnan(x).any(), torch.full_like(out, float("nan")), out)
     return (out, pair) if return_pair else out
 
 
@@ -91,6 +98,8 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
     if (n * x.element_size()) % 16 and B > 1:
         return torch.stack([percentile(x[i], pct) for i in range(B)])
     L = _bind()
+    if x.data_ptr() % 16:
+        x = x.clone()
     out = torch.empty(B, dtype=x.dtype, device=x.device)
     ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() + i * n * x.element_size() for i in range(B)])
     with torch.cuda.device(x.device):
@@ -98,13 +107,16 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
         st = L.mq_percentile_batch(ptrs, B, _DT[x.dtype], n, float(pct), out.data_ptr(), None, ws.data_ptr(),
                                    ws.numel(), stream.cuda_stream)
     _lib.check(st)
-    return out
+    # np.percentile returns NaN for a row that holds one (the select would rank it as the largest value)
+    return torch.where(torch.isnan(x).any(dim=1), torch.full_like(out, float("nan")), out)
 
 
 @torch.no_grad()
-def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0) -> torch.Tensor:
+def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: bool = True) -> torch.Tensor:
     """np.percentile(x, pct) for each of a list of non-negative float32 / float64 device tensors of one dtype
-    (any lengths; each flattened, contiguous and 16-byte aligned): one set of launches per 64 arrays."""
+    (any lengths; each flattened; unaligned views are copied): one set of launches per 64 arrays.  nan_check:
+    as for percentile() (one small reduction per array; callers that already know which arrays hold a NaN --
+    e.g. from their means -- pass False and patch the results themselves)."""
     if not xs:
         raise ValueError("percentile_multi() needs at least one array")
     dtype, dev = xs[0].dtype, xs[0].device
@@ -121,6 +133,7 @@ def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0) -> torch.Ten
             x = x.clone()
         flat.append(x)
     B = len(flat)
+    has_nan = torch.stack([torch.isnan(x).any() for x in flat]) if nan_check else None
     L = _bind()
     out = torch.empty(B, dtype=dtype, device=dev)
     ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() for x in flat])
@@ -130,6 +143,8 @@ def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0) -> torch.Ten
         st = L.mq_percentile_multi(ptrs, ns, B, _DT[dtype], float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                    stream.cuda_stream)
     _lib.check(st)
+    if has_nan is not None:
+        out = torch.where(has_nan, torch.full_like(out, float("nan")), out)
     return out
 
 

@@ -134,7 +134,10 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
             vec_rows += sel
             vecs += [per_vec[i] for i in range(len(sel))]
     for lo in range(0, len(vecs), 4096):
-        out[torch.as_tensor(vec_rows[lo:lo + 4096], device=dev), 4] = percentile_multi(vecs[lo:lo + 4096], pct)
+        out[torch.as_tensor(vec_rows[lo:lo + 4096], device=dev), 4] = percentile_multi(vecs[lo:lo + 4096], pct,
+                                                                                        nan_check=False)
+    # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
+    out[:, 4] = torch.where(torch.isnan(out[:, 3]), out[:, 3], out[:, 4])
     return out
 
 

@@ -267,3 +267,49 @@ def test_short_array_single_launch_route(em):
         srt = np.sort(arrays[4])
         k = (arrays[4].size - 1) * 0.99
         assert pair.cpu().numpy().tolist() == [srt[int(np.floor(k))], srt[int(np.ceil(k))]]
+
+
+def test_error_stats_any_column_count_and_offset_views(em, oracle):
+    """compute_errors(form="multi") -- the per-column loop of quant_error_multi_weight.py:67-78 -- accepts any
+    shape: a column count that is not a multiple of 8, storage that starts off a 16-byte boundary, an index
+    range with an odd start (the scalar column kernel and the flat totals sweep of mq_error_stats)."""
+    rng = np.random.default_rng(5)
+    for K, C, gs in [(37, 1001, None), (24, 1001, 143), (16, 1000, 125)]:
+        a = (rng.standard_normal((K, C)) * 0.02).astype(np.float16)
+        b = (a.astype(np.float32) + rng.standard_normal((K, C)).astype(np.float32) * 1e-3).astype(np.float16)
+        # device views whose first element is not 16-byte aligned
+        ta = torch.from_numpy(np.concatenate([np.zeros(3, np.float16), a.reshape(-1)])).cuda()[3:].view(K, C)
+        tb = torch.from_numpy(np.concatenate([np.zeros(5, np.float16), b.reshape(-1)])).cuda()[5:].view(K, C)
+        assert ta.data_ptr() % 16 and tb.data_ptr() % 16
+        grouping = "per-channel" if gs is None else "per-group"
+        got = em.compute_errors(ta, tb, grouping, gs, form="multi")
+        want = oracle.compute_errors_multi(oracle.proto_to_array(a), oracle.proto_to_array(b), grouping, gs)
+        for k in ("mse_tensor", "mse_rep", "mse_p99"):
+            assert abs(got[k] - want[k]) <= 1e-6 * abs(want[k]), (K, C, gs, k)
+    # a flat index range with an odd start and length (QuantizationErrorAnalyzer's sliced statistics)
+    x = torch.randn(300001, device="cuda").half()
+    y = (x.float() * 1.001).half()
+    st = em.error_stats(x[7:300000], y[7:300000])
+    e = (x[7:300000].float() - y[7:300000].float()).double()
+    torch.testing.assert_close(st["totals"], torch.stack([(e * e).sum(), e.abs().sum()]), rtol=1e-6, atol=0)
+
+
+def test_percentile_unaligned_views_and_nan(em):
+    """A sliced view (storage off a 16-byte boundary) is accepted, and an array holding a NaN gives NaN, as
+    np.percentile does."""
+    rng = np.random.default_rng(9)
+    x = np.abs(rng.standard_normal(100003)).astype(np.float32)
+    t = torch.from_numpy(x).cuda()
+    got = em.percentile(t[1:], 99)
+    assert got.cpu().numpy().tobytes() == np.percentile(x[1:], 99).astype(np.float32).tobytes()
+    got = em.percentile_multi([t[1:], t[3:50000]], 99).cpu().numpy()
+    assert got[0].tobytes() == np.percentile(x[1:], 99).astype(np.float32).tobytes()
+    assert got[1].tobytes() == np.percentile(x[3:50000], 99).astype(np.float32).tobytes()
+    x[777] = np.nan
+    t = torch.from_numpy(x).cuda()
+    assert torch.isnan(em.percentile(t, 99)) and np.isnan(np.percentile(x, 99))
+    m = em.percentile_multi([t, t[1000:]], 50).cpu().numpy()
+    assert np.isnan(m[0]) and m[1].tobytes() == np.percentile(x[1000:], 50).astype(np.float32).tobytes()
+    b = em.percentile_batch(torch.from_numpy(x[:100000].reshape(4, 25000)).cuda(), 99).cpu().numpy()
+    want = np.percentile(x[:100000].reshape(4, 25000), 99, axis=1).astype(np.float32)
+    assert np.isnan(b[0]) and np.array_equal(b[1:], want[1:])
