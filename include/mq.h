@@ -39,7 +39,8 @@ typedef enum {
   MQ_ERR_UNSUPPORTED = -3, /* bit width / format outside the supported set         -> ValueError   */
   MQ_ERR_WORKSPACE = -4,   /* workspace missing or smaller than mq_*_workspace_bytes               */
   MQ_ERR_HIP = -5,         /* a HIP call failed (see mq_last_hip_error)                            */
-  MQ_ERR_ALIGN = -6        /* a pointer is not aligned to its element size                         */
+  MQ_ERR_ALIGN = -6,       /* a pointer is not aligned to its element size                         */
+  MQ_ERR_TOO_LARGE = -7    /* a size beyond the fixed capacity of an allocation-free entry point  -> ValueError */
 } mq_status;
 
 /* How to quantize.  group_size follows the reference: -1 per-tensor, any other value <= 0 per-channel
@@ -248,6 +249,22 @@ size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t want_cols);
 int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,
                    void* abs_err, int32_t abs_err_dtype, double* seg_sse, double* col_sse, double* totals,
                    void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
+ * mq_error_stats without a caller workspace and without any allocation.  It has no counterpart in the reference;
+ * it is for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  The partial sums mq_error_stats keeps in its workspace live in a device
+ * array that is part of the library's code object instead: 4.25 MiB, held by every GPU the library runs on until
+ * the process ends, enough for col_sse over at most MQ_ERROR_STATS_STATIC_MAX_COLS columns (any number of rows;
+ * without col_sse any shape).  More columns return MQ_ERR_TOO_LARGE before anything is enqueued.  The call makes
+ * no hipMalloc / hipFree and calls no allocating routine; the array's address is looked up once per device.  All
+ * calls on one GPU share the array: calls that overlap there (different streams, different threads) race; calls
+ * on one stream are ordered as usual.  Arguments and results are those of mq_error_stats.
+ */
+#define MQ_ERROR_STATS_STATIC_MAX_COLS 8192
+int mq_error_stats_static(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,
+                          void* abs_err, int32_t abs_err_dtype, double* seg_sse, double* col_sse, double* totals,
+                          void* hip_stream);
 
 /*
  * idx[i] = min(np.digitize(abs_err[i], bins, right=True), nbins - 1) for a float16 |error| array

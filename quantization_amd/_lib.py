@@ -15,7 +15,7 @@ TABLE_F16, TABLE_F32, TABLE_MX = 0, 1, 2
 TABLE_MAX_VALUES = 256
 TABLE_NEG_INF_ZERO = 1
 
-OK, ERR_ARG, ERR_GROUP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_ALIGN = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_ARG, ERR_GROUP, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_HIP, ERR_ALIGN, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class QuantCfg(ctypes.Structure):
@@ -84,7 +84,7 @@ def check(status, shape_msg=None):
     if status == ERR_GROUP:
         # torch's reshape failure in the reference (quant_weight.py:253-255) is a RuntimeError
         raise RuntimeError(shape_msg or msg)
-    if status in (ERR_ARG, ERR_UNSUPPORTED):
+    if status in (ERR_ARG, ERR_UNSUPPORTED, ERR_TOO_LARGE):
         raise ValueError(msg)
     if status == ERR_HIP:
         raise MqError(f"{msg}: {L.mq_last_hip_error().decode()}")

@@ -23,6 +23,7 @@ extern "C" const char* mq_strerror(int status) {
     case MQ_ERR_WORKSPACE: return "workspace missing or too small";
     case MQ_ERR_HIP: return "HIP runtime error";
     case MQ_ERR_ALIGN: return "pointer not aligned to its element size";
+    case MQ_ERR_TOO_LARGE: return "size beyond the fixed capacity of this allocation-free entry point";
     default: return "unknown status";
   }
 }

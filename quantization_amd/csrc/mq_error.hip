@@ -459,6 +459,46 @@ extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64
                           workspace_bytes, static_cast<hipStream_t>(hip_stream));
 }
 
+// ---- the same without a caller workspace and without any allocation ---------------------------------------------
+// For callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): the
+// per-workgroup partial sums and the partial column sums live in one device array of this code object, sized for
+// at most MQ_ERROR_STATS_STATIC_MAX_COLS columns.  Every GPU holds its own copy of the array for the life of the
+// process; its address is looked up once per device (with that device current) and used from then on -- the
+// array's name itself is only a host-side handle.  Calls that overlap on one GPU share the array and race.
+static const size_t kStaticScratchBytes =
+    (size_t)kErrMaxGrid * 2 * sizeof(double) + (size_t)64 * MQ_ERROR_STATS_STATIC_MAX_COLS * sizeof(double);
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+#include <mutex>
+static const int kMaxDevices = 64;
+static void* scratch_ptr[kMaxDevices];  // per device, null until looked up
+static std::mutex scratch_mu;
+
+static int static_scratch(void** out) {
+  int dev = -1;
+  MQ_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return MQ_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(scratch_mu);
+  if (!scratch_ptr[dev]) {
+    void* q = nullptr;
+    MQ_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)));  // this device's copy of the array
+    scratch_ptr[dev] = q;
+  }
+  *out = scratch_ptr[dev];
+  return MQ_OK;
+}
+
+extern "C" int mq_error_stats_static(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols,
+                                     int64_t seg_len, void* abs_err, int32_t abs_err_dtype, double* seg_sse,
+                                     double* col_sse, double* totals, void* hip_stream) {
+  if (rows < 0 || cols < 0) return MQ_ERR_ARG;
+  if (col_sse && cols > MQ_ERROR_STATS_STATIC_MAX_COLS) return MQ_ERR_TOO_LARGE;
+  void* ws = nullptr;
+  if (int rc = static_scratch(&ws)) return rc;
+  // (nothing in the array has to start at zero: every slot the finishing kernels read is written by this call)
+  return error_stats_impl(a, b, dtype, rows, cols, seg_len, abs_err, abs_err_dtype, seg_sse, col_sse, totals, ws,
+                          kStaticScratchBytes, static_cast<hipStream_t>(hip_stream));
+}
+
 extern "C" int mq_bucketize_f16(const void* abs_err_f16, int64_t n, const double* bins_host, int32_t nbins,
                                 uint8_t* idx, void* hip_stream) {
   if (n < 0 || nbins < 1 || nbins > 64 || !bins_host) return MQ_ERR_ARG;
