@@ -1,25 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the quantize -> dequantize -> error hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|tinyllama|llama8b|llama70b]
-                    [--dist normal|student_t]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--workload llama8b|llama70b|tinyllama|c2|c3|llama70b_shard] [--dist normal|student_t]
 
-For N > 1 the driver starts one rank per GPU with torch.distributed.run; every rank processes its own
-copy of the workload (weak scaling: the units are independent weight tensors, no data-path collective)
-and the per-tensor statistics records are all-gathered once per step over RCCL.
+Headline workload "llama8b" (BASELINE.json configs[3]): all 225 linear weights of Llama-3-8B (random-init bf16,
+15.0 GB), symmetric int8 error statistics per-channel and per-group g = 32 / 64 / 128 -- four passes over the
+model per step -- with the layers SHARDED over the N ranks (greedy longest-processing-time on the element
+count; no weight crosses GPUs).  Per rank a pass is one fused launch per group of same-shaped layers
+(report.model_records); per step RCCL carries one all-reduce of the per-layer record table
+(distributed.gather_records) and the histogram all-reduces of one model-wide P99 taken jointly over every
+rank's per-channel MSE lists (distributed.joint_percentile).  "llama70b" (configs[4]) is the same over the 561
+weights of Llama-3-70B (139 GB) with int8 sym / asym, fp8_e4m3, fp8_e3m4 x {per-channel, g = 32 / 64 / 128};
+"tinyllama" (configs[0]) per-channel int8 on fp16 weights.  The total work is fixed as N grows ("strong").
 
-Default workload "c2" (BASELINE.json configs[1]): 4096x4096 fp16 matrices, asymmetric int8 with
-group sizes 32 / 64 / 128, returning dequantized weights, codes, scales, zero-points and the float32
-element-wise absolute-error dump, plus per-group and per-tensor squared-error sums, the mean and exact
-P99 of the per-group MSE vector and the exact P99 of the absolute error.  A step is one
-pass over a batch of 16 distinct matrices (512 MiB of weights, 5.4 GB of outputs -- more than the
-256 MiB Infinity Cache, so inputs come from HBM) x 3 group sizes = 48 tensor passes in 3 batched launches.
+--gpus N without a launcher starts N ranks itself (fresh child processes through torch.distributed.run, before
+this process touches a GPU); under torch.distributed.run it must equal WORLD_SIZE.  MQ_BENCH_BACKEND=gloo
+rehearses the multi-rank path on a box with fewer GPUs than ranks.
 
-Other workloads (BASELINE.json configs[0], [2], [3], [4]; not the headline line): "tinyllama" / "llama8b" --
-all linear weights of that shape list, int8-sym per-channel, statistics only; "c3" -- TinyLlama shapes, int8-sym /
-fp8_e4m3 / fp8_e3m4 per-channel dequantized + the element-wise best-format masks of elwise_error/compare.py;
-"llama70b" -- one GPU's eighth of the Llama-3-70B linear layers (10 decoder layers, 17 GB bf16), int8 sym / asym,
-fp8_e4m3, fp8_e3m4 x {per-channel, g = 32 / 64 / 128}, statistics only.
+At N = 1 the same JSON line carries two more driver-timed results under "extra": "c2" (configs[1]: 16 x
+4096 x 4096 fp16, asymmetric int8 g = 32 / 64 / 128 with dequantized weights, codes, scales, zero-points, the
+float32 |error| dump and its exact P99 selected inside the pass) and "llama70b_shard" (one GPU's eighth of the
+Llama-3-70B sweep), each with its own roofline object; and the CPU baseline.
 
 One JSON line is printed by rank 0.
 """
@@ -27,56 +29,150 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import quantization_amd as qa  # noqa: E402
-from quantization_amd import _lib  # noqa: E402
-from quantization_amd.error_metrics import percentile_multi, true_div  # noqa: E402
-from quantization_amd.fused import QuantResult, quantize_batch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+MODEL_OF = {"llama8b": "llama-3-8b", "llama70b": "llama-3-70b", "tinyllama": "tinyllama-1.1b"}
+GROUPS = (None, 32, 64, 128)
+REFERENCE_BUILD_CONTAINER = {
+    # the reference itself (imported quant_weight._int_quant_meta on torch CPU + the scripts' numpy arithmetic) on
+    # the c2 unit of work, timed in the build container by scratch/ref_time.py; /root/reference does not exist
+    # on the GPU box, so this number cannot be re-measured there
+    "value": 0.052, "unit": "GB/s", "cores": 8, "where": "build container (8 cores, torch CPU 8 threads)",
+    "sample": "one 4096x4096 fp16 matrix x g=32/64/128, asymmetric int8 + float32 error, MSE, |err| sum and P99"}
 
-TINYLLAMA = [(2048, 2048)] * 2 + [(256, 2048)] * 2 + [(5632, 2048)] * 2 + [(2048, 5632)]
-LLAMA8B = [(4096, 4096)] * 2 + [(1024, 4096)] * 2 + [(14336, 4096)] * 2 + [(4096, 14336)]
-LLAMA70B = [(8192, 8192)] * 2 + [(1024, 8192)] * 2 + [(28672, 8192)] * 2 + [(8192, 28672)]
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="llama8b",
+                    choices=["llama8b", "llama70b", "tinyllama", "c2", "c3", "llama70b_shard"])
+    ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the c2 and llama70b_shard results")
+    return ap.parse_args()
 
 
-def model_shapes(per_layer, layers, head):
-    return per_layer * layers + [head]
+def spawn_ranks(args):
+    """--gpus N from a plain `python bench.py`: start N ranks as fresh children; this process never touches a GPU."""
+    import torch
+    if os.environ.get("MQ_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
-def algorithmic_bytes_per_elem(in_bytes, fmt, gs, outputs):
+def algorithmic_bytes_per_elem(in_bytes, lut, asym, gs, outputs):
     """HBM bytes one fused launch must move per weight element: input once, plus each requested output."""
+    import torch
     b = float(in_bytes)
     if outputs.get("deq"):
         b += 2
     if outputs.get("codes"):
-        b += 2 if fmt == _lib.LUT_FP else 1
+        b += 2 if lut else 1
     if outputs.get("abs_err") == torch.float32:
         b += 4
     elif outputs.get("abs_err") == torch.float16:
         b += 2
     if gs and gs > 0:
-        per_seg = (2 if outputs.get("scale") else 0) * (2 if fmt == _lib.INT_ASYM else 1)
+        per_seg = (2 if outputs.get("scale") else 0) * (2 if asym else 1)
         per_seg += 8 if outputs.get("seg_sse") else 0
         b += per_seg / gs
     return b
 
 
+class ModelSweep:
+    """The sharded model sweep (configs [0], [3], [4]): this rank's layers of the model, every pass of the sweep."""
+
+    def __init__(self, name, device, rank, world, dist_name):
+        import torch
+        from quantization_amd import shapes
+        from quantization_amd.distributed import lpt_partition
+        self.name, self.device, self.rank, self.world = name, device, rank, world
+        model = MODEL_OF[name]
+        self.layers = shapes.linear_shapes(model)
+        self.dtype = torch.float16 if name == "tinyllama" else torch.bfloat16
+        if name == "llama70b":
+            fmts = [("int8", 8), ("int8_asym", 8), ("fp8_e4m3", 8), ("fp8_e3m4", 8)]
+            self.passes = [(f, b, gs) for f, b in fmts for gs in GROUPS]
+        elif name == "llama8b":
+            self.passes = [("int8", 8, gs) for gs in GROUPS]
+        else:
+            self.passes = [("int8", 8, None)]
+        sizes = [r * c for _, (r, c) in self.layers]
+        self.mine = lpt_partition(sizes, world)[rank]
+        self.weights = [shapes.synthetic_weight(i, self.layers[i][1], self.dtype, device, dist=dist_name) for i in self.mine]
+        esz = 2
+        self.local_elems = sum(sizes[i] for i in self.mine)
+        self.total_weight_bytes = sum(sizes) * esz * len(self.passes)          # whole job, every pass counts
+        self.local_weight_bytes = self.local_elems * esz * len(self.passes)
+        stats = dict(seg_sse=True)
+        self.local_algo_bytes = sum(
+            sizes[i] * algorithmic_bytes_per_elem(esz, f.startswith("fp"), "asym" in f, gs, stats)
+            + (8 * self.layers[i][1][0] if gs is None else 0)                  # per-row sums of the per-channel passes
+            for i in self.mine for f, _, gs in self.passes)
+        self.launches_hint = sum(-(-sum(1 for i in self.mine if self.layers[i][1] == sh) // 32)
+                                 for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
+        self.n_layers = len(self.layers)
+        f0, _, g0 = self.passes[0]   # the lists of the first pass feed the model-wide percentile
+        self.total_vectors = sum(r if g0 is None else r * c // g0 for _, (r, c) in self.layers)
+        self.index = torch.as_tensor([p * self.n_layers + i for p in range(len(self.passes)) for i in self.mine],
+                                     dtype=torch.int64, device=device)
+        fm = ", ".join(sorted({f for f, _, _ in self.passes}))
+        self.desc = (f"{model}: {self.n_layers} linear weights ({sum(sizes) * esz / 1e9:.1f} GB {str(self.dtype).split('.')[-1]}, "
+                     f"{dist_name} scale 0.02), {fm} x per-channel / g=32 / 64 / 128 error statistics"
+                     if len(self.passes) > 1 else
+                     f"{model}: {self.n_layers} linear weights ({sum(sizes) * esz / 1e9:.1f} GB {str(self.dtype).split('.')[-1]}, "
+                     f"{dist_name} scale 0.02), int8 per-channel error statistics")
+        self.desc += (" (per-layer tensor MSE, mean and exact P99 of the per-vector MSE list; one model-wide P99 over all "
+                      f"layers' per-channel lists), layers sharded over {world} rank(s) by longest-processing-time")
+        self.kernel_desc = "statistics-only fused quantize pass (k_stats_row / k_stats_group: one launch per group of same-shaped layers)"
+
+    def step(self):
+        import torch
+        from quantization_amd.distributed import gather_records, joint_percentile
+        from quantization_amd.report import RECORD_FIELDS, model_records
+        recs, vecs = [], []
+        for k, (fmt, bits, gs) in enumerate(self.passes):
+            if not self.weights:
+                break
+            if k == 0:   # the per-channel lists of the first format feed the model-wide percentile
+                r, vecs = model_records(self.weights, fmt, bits, gs, abs_p99=False, return_vecs=True)
+            else:
+                r = model_records(self.weights, fmt, bits, gs, abs_p99=False)
+            recs.append(r)
+        local = torch.cat(recs) if recs else None
+        # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
+        table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
+        # ... and the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists
+        model_p99 = joint_percentile(vecs, 99.0, dtype=torch.float64, total=self.total_vectors)
+        return table, model_p99
+
+
 class Workload:
-    """Passes are grouped into batches of same-shaped tensors: one fused launch (per 32 tensors) quantizes a
-    whole batch, one set of select launches takes all its P99s."""
+    """Single-GPU workloads: passes are grouped into batches of same-shaped tensors: one fused launch (per 32
+    tensors) quantizes a whole batch, one set of select launches takes all its P99s."""
 
     def __init__(self, name, device, rank, dist_name="normal"):
+        import torch
+        from quantization_amd import _lib
         self.name = name
         g = torch.Generator(device=device)
+        TINYLLAMA = [(2048, 2048)] * 2 + [(256, 2048)] * 2 + [(5632, 2048)] * 2 + [(2048, 5632)]
+        LLAMA70B = [(8192, 8192)] * 2 + [(1024, 8192)] * 2 + [(28672, 8192)] * 2 + [(8192, 28672)]
 
         def draw(shape, dtype):
             """N(0, 0.02^2), or Student-t (3 degrees of freedom) scaled by 0.02: the heavy-tailed case."""
@@ -92,7 +188,7 @@ class Workload:
         self.batches = []  # (stacked weights [B, rows, cols], fmt, datatype, gs, outputs dict)
         self.results = {}
         if name == "c2":
-            self.desc = (f"16x 4096x4096 fp16 {dist_name} (scale 0.02), int8-asym g=32/64/128: deq + codes + scale + zp + "
+            self.desc = (f"c2: 16x 4096x4096 fp16 {dist_name} (scale 0.02), int8-asym g=32/64/128: deq + codes + scale + zp + "
                          "abs-err(f32) dump + per-group/tensor MSE + exact P99 of |err| and of the per-group MSE")
             outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True, totals=True)
             g.manual_seed(1000 * rank)
@@ -100,32 +196,25 @@ class Workload:
             for gs in (32, 64, 128):
                 self.batches.append((w, _lib.INT_ASYM, None, gs, outs))
         else:
-            if name in ("tinyllama", "c3"):
-                shapes, dt = model_shapes(TINYLLAMA, 22, (32000, 2048)), torch.float16
-            elif name == "llama8b":
-                shapes, dt = model_shapes(LLAMA8B, 32, (128256, 4096)), torch.bfloat16
+            if name == "c3":
+                shapes, dt = TINYLLAMA * 22 + [(32000, 2048)], torch.float16
             else:   # one GPU's share of the 80 decoder layers (the 561-tensor model split over 8 GPUs)
                 shapes, dt = LLAMA70B * 10, torch.bfloat16
-            stats = dict(deq=False, codes=False, scale=True, abs_err=None, seg_sse=True, totals=True)
+            stats = dict(deq=False, codes=False, scale=False, abs_err=None, seg_sse=True, totals=True)
             if name == "c3":
                 passes = [(_lib.INT_SYM, None, None), (_lib.LUT_FP, "fp8_e4m3", None), (_lib.LUT_FP, "fp8_e3m4", None)]
                 outs = dict(deq=True, codes=False, scale=False, abs_err=None, seg_sse=False, totals=True)
                 self.compare = []
-                self.desc = (f"TinyLlama-shaped {dist_name} fp16 linear weights ({len(shapes)} tensors): int8-sym, fp8_e4m3, "
+                self.desc = (f"c3: TinyLlama-shaped {dist_name} fp16 linear weights ({len(shapes)} tensors): int8-sym, fp8_e4m3, "
                              "fp8_e3m4 per-channel dequantized weights + tensor MSE, then the element-wise best-format / "
                              "outlier masks of compare.py")
-            elif name == "llama70b":
-                passes = [(f, d, gs) for f, d in ((_lib.INT_SYM, None), (_lib.INT_ASYM, None), (_lib.LUT_FP, "fp8_e4m3"),
-                                                  (_lib.LUT_FP, "fp8_e3m4")) for gs in (None, 32, 64, 128)]
-                outs = stats
-                self.desc = (f"1/8 of Llama-3-70B's linear layers ({len(shapes)} tensors, bf16 {dist_name}): int8 sym / asym, "
-                             "fp8_e4m3, fp8_e3m4 x per-channel / g=32 / 64 / 128, stats only (per-vector/tensor MSE, "
-                             "sum|err|, exact P99 of the per-vector MSE)")
             else:
-                passes = [(_lib.INT_SYM, None, None)]
+                passes = [(f, d, gs) for f, d in ((_lib.INT_SYM, None), (_lib.INT_ASYM, None), (_lib.LUT_FP, "fp8_e4m3"),
+                                                  (_lib.LUT_FP, "fp8_e3m4")) for gs in GROUPS]
                 outs = stats
-                self.desc = (f"{name}-shaped random-init {str(dt).split('.')[-1]} linear weights ({len(shapes)} tensors), "
-                             "int8-sym per-channel, stats only (per-row/tensor MSE, sum|err|, exact P99 of the per-row MSE)")
+                self.desc = (f"llama70b_shard: 1/8 of Llama-3-70B's linear layers ({len(shapes)} tensors, 17.1 GB bf16 {dist_name}): "
+                             "int8 sym / asym, fp8_e4m3, fp8_e3m4 x per-channel / g=32 / 64 / 128 error statistics "
+                             "(per-vector/tensor MSE, sum|err|, exact P99 of the per-vector MSE)")
             groups = {}
             for sh in shapes:
                 groups[sh] = groups.get(sh, 0) + 1
@@ -140,17 +229,20 @@ class Workload:
                     if self.compare is not None:
                         self.compare.append((w, list(range(first, first + len(passes))),
                                              torch.empty(w.shape, dtype=torch.uint8, device=device)))
-        self.kernel_desc = ("fused quantize pass (k_quant_team/wave/block: one launch per batch of same-shaped tensors"
-                            + (", feeding the P99 selection)" if name == "c2" else ")"))
+        self.kernel_desc = ("fused quantize pass (k_quant_team: one launch per batch of same-shaped tensors, feeding the "
+                            "P99 selection)" if name == "c2" else
+                            "statistics-only fused quantize pass (k_stats_row / k_stats_group)" if name == "llama70b_shard"
+                            else "fused quantize pass (k_quant_wave / k_quant_block: dequantized weights)")
         self.tensors = sum(w.shape[0] for w, *_ in self.batches)
         # weight bytes of a step: every pass over a tensor counts (a sweep quantizes the same weights per format)
         self.weight_bytes = sum(w.numel() * w.element_size() for w, *_ in self.batches)
-        self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f, gs, o)
+        self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f in (_lib.LUT_FP, _lib.LUT_FP_SUB),
+                                                                     f == _lib.INT_ASYM, gs, o)
+                              + (8 * w.shape[0] * w.shape[1] if (gs is None and o.get("seg_sse")) else 0)
                               for w, f, _, gs, o in self.batches)
         self.launches = len(self.batches)
         self.device = device
         self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
-        # per-tensor constants of the statistics step, resident on the device
         lens, counts = [], []
         for w, fmt, dt, gs, outs in self.batches:
             L = gs if gs else w.shape[2]
@@ -163,10 +255,11 @@ class Workload:
     def step(self):
         """All fused quantize launches of the step, then ONE set of select launches per dtype for the P99s of
         every tensor of the step (the chains of short kernels run once per step, not once per batch)."""
+        import torch
+        from quantization_amd.error_metrics import percentile_multi, true_div
+        from quantization_amd.fused import QuantResult, quantize_batch
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
-            # one preallocated output set per batch: outputs cycle through > 256 MiB so they reach HBM; the
-            # [sum err^2, sum |err|] pairs of all batches land in one table
             res = self.results.get(k)
             if res is None:
                 res = QuantResult(0, 0, 0)
@@ -184,153 +277,209 @@ class Workload:
             for w, idxs, flags in self.compare:
                 compare_formats(w, [results[i].deq for i in idxs], 0.02, out=flags)
             rec[:, 0:2] = self.totals
-            return [rec]
+            return rec
         rec[:, 0:2] = self.totals
-        # mean of the per-(row, group) / per-row MSE list = sum of squares / (L * nseg): equal lengths
         rec[:, 2] = self.totals[:, 0] / self.numel
-        # exact P99 of every per-vector MSE list (float64 select).  A power-of-two L divides after the select
-        # (an exponent shift commutes with it); any other length divides its list first (IEEE division, as the
-        # scripts divide), per batch.
         vecs = []
         for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
             L = gs if gs else w.shape[2]
             per_vec = res.seg_sse if L & (L - 1) == 0 else true_div(res.seg_sse, L)
             vecs += [per_vec[i] for i in range(per_vec.shape[0])]
-        rec[:, 3] = percentile_multi(vecs, 99) / self.post_div
+        rec[:, 3] = percentile_multi(vecs, 99, nan_check=False) / self.post_div
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
-        return [rec]
+        return rec
 
 
-def cpu_baseline(nthreads):
-    """The CPU port (oracle/: C restatement of quant_weight.py + the analysis scripts' numpy) on a bounded
-    sample of the c2 workload: ONE 4096x4096 fp16 matrix x g = 32 / 64 / 128, asymmetric int8 with
-    deq/codes/scale/zp, float32 error, tensor MSE, abs-error sum and P99, per-group MSE vector + P99."""
+def cpu_baseline():
+    """The CPU port (oracle/: C restatement of quant_weight.py + the analysis scripts' numpy) on a bounded sample of
+    the headline workload: ONE 4096 x 4096 bf16 matrix x {per-channel, g = 32 / 64 / 128}, symmetric int8, tensor
+    MSE, per-vector MSE list, its mean and P99 -- timed with one thread and with the CPU share this box gives a
+    one-GPU job."""
+    import numpy as np
     from oracle import oracle as orc
     rng = np.random.default_rng(0)
-    w = (rng.standard_normal((4096, 4096)) * 0.02).astype(np.float16)
-    orc.quantize(w[:64], orc.F16, orc.INT_ASYM, 8, 128, nthreads=nthreads)  # load the library
-    t0 = time.perf_counter()
-    passes = 0
-    while time.perf_counter() - t0 < 10.0:   # bounded sample: whole 3-pass sweeps until 10 s have gone
-        for gs in (32, 64, 128):
-            o = orc.quantize(w, orc.F16, orc.INT_ASYM, 8, gs, nthreads=nthreads)
-            deq = o["deq"].view(np.float16)
-            a32, b32 = orc.proto_to_array(w), orc.proto_to_array(deq)
-            orc.compute_mse(a32, b32)
-            orc.elementwise_f32(w, deq)            # float32 |err|, its sum and np.percentile(., 99)
-            # per-(row, group) MSE vector + mean + P99 (quant_error_single_weight.py:61-79), vectorised
-            d = (a32 - b32).reshape(-1, gs)
-            vec = np.mean(d * d, axis=1, dtype=np.float32).astype(np.float64)
-            vec.mean(), np.percentile(vec, 99)
-            passes += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(passes * w.nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": nthreads, "kind": "port",
-            "sample": f"one 4096x4096 fp16 matrix x g=32/64/128, {passes} passes in {dt:.1f} s: C oracle quantize "
-                      f"({nthreads} OpenMP threads) + numpy MSE / abs-err sum / P99 / per-group MSE vector + P99"}
+    w32 = (rng.standard_normal((4096, 4096)) * 0.02).astype(np.float32)
+    wbf = (w32.view(np.uint32) >> 16).astype(np.uint16)            # bfloat16 bits (truncation is fine for a timing input)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+
+    def sweep(nthreads, budget):
+        orc.quantize(wbf[:64], orc.BF16, orc.INT_SYM, 8, 128, nthreads=nthreads)  # load the library
+        t0, passes = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget:
+            for gs in GROUPS:
+                o = orc.quantize(wbf, orc.BF16, orc.INT_SYM, 8, gs, nthreads=nthreads)
+                a32 = o["v16"].view(np.float16).astype(np.float32)
+                b32 = o["deq"].view(np.float16).astype(np.float32)
+                orc.compute_mse(a32, b32)
+                d = (a32 - b32).reshape(-1, gs or 4096)
+                vec = np.mean(d * d, axis=1, dtype=np.float32).astype(np.float64)   # single_weight.py:61-79, vectorised
+                vec.mean(), np.percentile(vec, 99)
+                passes += 1
+        return passes * wbf.nbytes / (time.perf_counter() - t0) / 1e9, passes
+
+    one, n1 = sweep(1, 6.0)
+    many, nm = sweep(share, 8.0)
+    return {"value": round(many, 4), "unit": "GB/s", "cores": share, "kind": "port",
+            "host_cpu_count": os.cpu_count(), "value_1_thread": round(one, 4),
+            "sample": f"one 4096x4096 bf16 matrix x per-channel / g=32 / 64 / 128 symmetric int8: C oracle quantize + numpy "
+                      f"tensor MSE + per-vector MSE list, mean, P99; {nm} passes with {share} OpenMP threads (the CPU share "
+                      f"of a one-GPU job on this box; the host has {os.cpu_count()} CPUs), {n1} passes with 1 thread",
+            "reference_build_container": REFERENCE_BUILD_CONTAINER}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "tinyllama", "llama8b", "llama70b"])
-    ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        # one rank per GPU over RCCL; MQ_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs
-        backend = os.environ.get("MQ_BENCH_BACKEND", "nccl")
-        local_rank %= max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    device = torch.device("cuda", torch.cuda.current_device())
-    _lib.lib()
-
-    wl = Workload(args.workload, device, rank, args.dist)
-    gathered = torch.zeros(world * wl.tensors, 5, dtype=torch.float64, device=device) if world > 1 else None
-
-    def one_step():
-        stats = wl.step()
-        if world > 1:
-            # per-tensor statistics records of every rank -> every rank, one RCCL collective per step
-            dist.all_gather_into_tensor(gathered, torch.cat(stats))
-
-    for _ in range(args.warmup):
-        one_step()
+def timed_run(step, steps, warmup, device, dist, world, reserve):
+    """W warm-up steps, then K steps between barrier + synchronize pairs; -> (wall max over ranks, GPU event ms,
+    summed dominant-kernel ms, dominant-kernel launches)."""
+    import torch
+    from quantization_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.mq_profile_reserve(int(reserve * (steps + 1)) + 64))
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    L = _lib.lib()
     _lib.check(L.mq_profile_begin())
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        one_step()
+    for _ in range(steps):
+        step()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    gpu_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
-
-    # dominant kernel: the full quantize launches of the timed region itself, each bracketed by a pair of HIP
-    # events on the launch stream inside the library (mq_profile_begin / mq_profile_end)
     kern_total_ms, kern_launches = ctypes.c_double(0), ctypes.c_int64(0)
     _lib.check(L.mq_profile_end(ctypes.byref(kern_total_ms), ctypes.byref(kern_launches)))
-    kern_ms = kern_total_ms.value / max(1, kern_launches.value)
-    algo_per_launch = wl.algo_bytes / wl.launches
-    achieved = algo_per_launch / (kern_ms * 1e-3) / 1e9
+    return float(tmax.item()), ev0.elapsed_time(ev1), kern_total_ms.value, kern_launches.value
 
+
+def roofline(algo_bytes_per_step, steps, kern_ms, launches, kernel_desc, traffic):
+    per_launch = algo_bytes_per_step * steps / max(1, launches)
+    avg_ms = kern_ms / max(1, launches)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel_desc,
+            "launches_timed": int(launches), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "algorithmic_bytes_per_launch": int(per_launch)}
+
+
+def traffic_for(name):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        return json.load(open(tpath)).get(name)
+    return None
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    import torch
+    from quantization_amd import _lib
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MQ_BENCH_BACKEND", "nccl")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            if torch.cuda.device_count() < world:
+                print(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+                sys.exit(2)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:   # rehearsal: ranks may share a GPU
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+            dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+    _lib.lib()
+
+    sharded = args.workload in MODEL_OF
+    if sharded:
+        wl = ModelSweep(args.workload, device, rank, world, args.dist)
+        total_weight_bytes, local_algo, reserve = wl.total_weight_bytes, wl.local_algo_bytes, wl.launches_hint
+    else:
+        if world > 1:
+            print(f"bench.py: workload {args.workload} is a single-GPU workload", file=sys.stderr)
+            sys.exit(2)
+        wl = Workload(args.workload, device, rank, args.dist)
+        total_weight_bytes, local_algo, reserve = wl.weight_bytes, wl.algo_bytes, wl.launches
+    wall, gpu_ms, kern_ms, kern_launches = timed_run(wl.step, args.steps, args.warmup, device, dist, world, reserve)
+
+    # per-rank shares, for the record
+    shares = None
+    if sharded:
+        mine = torch.tensor([wl.local_weight_bytes, len(wl.mine)], dtype=torch.int64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        shares = [[int(v) for v in t.tolist()] for t in allr]
+
+    out = None
     if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.workload)
         out = {
             "metric": "weight GB/s quant+dequant+MSE/P99",
-            "value": round(world * wl.weight_bytes * args.steps / wall / 1e9, 2),
+            "value": round(total_weight_bytes * args.steps / wall / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f16",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {wl.desc}", "fused_launches_per_step": wl.launches,
-                       "tensor_passes_per_step": wl.tensors,
-                       "weight_bytes_per_step_per_gpu": wl.weight_bytes,
-                       "algorithmic_bytes_per_step_per_gpu": int(wl.algo_bytes),
-                       "gpu_ms_per_step_events": round(gpu_ms / args.steps, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": wl.kernel_desc, "launches_timed": int(kern_launches.value), "avg_launch_us": round(kern_ms * 1e3, 2),
-                         "algorithmic_bytes_per_launch": int(algo_per_launch)},
+            "config": {"workload": f"{args.workload}: {wl.desc}",
+                       "passes_per_step": len(wl.passes) if sharded else wl.launches,
+                       "weight_bytes_per_step_whole_job": int(total_weight_bytes),
+                       "gpu_ms_per_step_events_rank0": round(gpu_ms / args.steps, 4)},
+            "roofline": roofline(local_algo, args.steps, kern_ms, kern_launches, wl.kernel_desc + " (rank 0)",
+                                 traffic_for(args.workload)),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 16))
+        if sharded:
+            out["config"].update({
+                "backend": backend if world > 1 else "none (one rank)",
+                "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0,
+                "collectives_per_step": "1 all-reduce of the record table + 4 histogram all-reduces (float64 joint P99)"
+                if world > 1 else "none",
+                "weight_bytes_per_step_per_rank": [s[0] for s in shares], "layers_per_rank": [s[1] for s in shares]})
+
+    # N = 1: the other two driver-timed results and the CPU baseline
+    if world == 1 and rank == 0 and sharded and args.workload == "llama8b" and not args.no_extra:
+        del wl
+        torch.cuda.empty_cache()
+        out["extra"] = {}
+        for name, steps, warm in (("c2", 20, 3), ("llama70b_shard", 3, 1)):
+            w2 = Workload(name, device, 0, args.dist)
+            wall2, gpu2, k2, n2 = timed_run(w2.step, steps, warm, device, None, 1, w2.launches)
+            out["extra"][name] = {
+                "value": round(w2.weight_bytes * steps / wall2 / 1e9, 2), "unit": "GB/s", "steps": steps, "warmup": warm,
+                "ms_per_step": round(wall2 / steps * 1e3, 4), "workload": w2.desc,
+                "weight_bytes_per_step": int(w2.weight_bytes),
+                "roofline": roofline(w2.algo_bytes, steps, k2, n2, w2.kernel_desc, traffic_for(name))}
+            del w2
+            torch.cuda.empty_cache()
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -3,8 +3,11 @@
  *
  * Plain C: raw device pointers, sizes, a HIP stream handle passed as void*.  No C++ or torch types.
  * Every function enqueues on the caller's stream and returns without synchronising unless it says
- * otherwise.  All buffers are allocated by the caller; the library keeps no pointer past the call and
- * has no global mutable state.  Functions return MQ_OK (0) or a negative mq_status and never throw.
+ * otherwise.  All buffers are allocated by the caller and the library keeps no pointer to them past the call.
+ * State the library does keep: per calling thread, the last HIP error text, the event pool of the
+ * mq_profile_* hook and a small cache of verified reciprocal constants; per process, the grid cap read once
+ * from the environment variable MQ_MAX_BLOCKS (tuning runs) and, per device, the address of the static scratch
+ * array of mq_error_stats_static.  Functions return MQ_OK (0) or a negative mq_status and never throw.
  *
  * "Reference" citations are into /root/reference (weirdmaverick/quantization).
  */
@@ -81,8 +84,11 @@ const char* mq_last_hip_error(void);
  * Measurement hook (no counterpart in the reference): between mq_profile_begin and mq_profile_end every full
  * quantize launch made from the calling thread (the dominant kernel of mq_quantize / mq_quantize_batch /
  * mq_quantize_p99_batch; not the 1/32 sampling pass) is bracketed by a pair of HIP events on its stream.
- * mq_profile_end waits for them and returns the summed kernel time and the number of launches.
+ * mq_profile_end waits for them and returns the summed kernel time and the number of launches.  The events come
+ * from a per-thread pool that outlives the run; mq_profile_reserve(launches) creates them ahead of time so that
+ * no event is created between begin and end.
  */
+int mq_profile_reserve(int64_t launches);
 int mq_profile_begin(void);
 int mq_profile_end(double* total_ms, int64_t* launches);
 

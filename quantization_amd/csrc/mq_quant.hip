@@ -1881,13 +1881,25 @@ void mq_launch_fmt3(int, int, int, int, int, dim3, size_t, hipStream_t, const Qu
 void mq_launch_fmt4(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
+// State of the calling thread: a pool of events that is created outside the timed region (mq_profile_reserve, or
+// on first use) and reused by every later mq_profile_begin; prof_used counts the events of the current run.
 #include <vector>
 static thread_local bool prof_on = false;
-static thread_local std::vector<hipEvent_t> prof_events;  // start, stop, start, stop, ...
+static thread_local std::vector<hipEvent_t> prof_pool;  // start, stop, start, stop, ...
+static thread_local size_t prof_used = 0;
+
+extern "C" int mq_profile_reserve(int64_t launches) {
+  if (launches < 0) return MQ_ERR_ARG;
+  while (prof_pool.size() < (size_t)launches * 2) {
+    hipEvent_t e;
+    MQ_HIP(hipEventCreate(&e));
+    prof_pool.push_back(e);
+  }
+  return MQ_OK;
+}
 
 extern "C" int mq_profile_begin(void) {
-  for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
-  prof_events.clear();
+  prof_used = 0;
   prof_on = true;
   return MQ_OK;
 }
@@ -1896,17 +1908,27 @@ extern "C" int mq_profile_end(double* total_ms, int64_t* launches) {
   prof_on = false;
   double sum = 0.0;
   int64_t cnt = 0;
-  for (size_t i = 0; i + 1 < prof_events.size(); i += 2) {
-    MQ_HIP(hipEventSynchronize(prof_events[i + 1]));
+  int rc = MQ_OK;
+  for (size_t i = 0; i + 1 < prof_used && rc == MQ_OK; i += 2) {
     float ms = 0.f;
-    MQ_HIP(hipEventElapsedTime(&ms, prof_events[i], prof_events[i + 1]));
+    if (hipEventSynchronize(prof_pool[i + 1]) != hipSuccess || hipEventElapsedTime(&ms, prof_pool[i], prof_pool[i + 1]) != hipSuccess) {
+      rc = MQ_ERR_HIP;
+      break;
+    }
     sum += ms;
     ++cnt;
   }
-  for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
-  prof_events.clear();
+  prof_used = 0;  // (the events stay in the pool for the next run)
   if (total_ms) *total_ms = sum;
   if (launches) *launches = cnt;
+  return rc;
+}
+// the next pair of pooled events, created here only if the pool was not reserved far enough
+static int prof_next_pair(hipEvent_t* e0, hipEvent_t* e1) {
+  if (int rc = mq_profile_reserve((int64_t)(prof_used / 2 + 1))) return rc;
+  *e0 = prof_pool[prof_used];
+  *e1 = prof_pool[prof_used + 1];
+  prof_used += 2;
   return MQ_OK;
 }
 
@@ -2060,13 +2082,10 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     hipLaunchKernelGGL(k_tensor_reduce, dim3((unsigned)(rb < cap ? rb : cap), (unsigned)count), dim3(256), 0, st, b);
   }
   const bool timed = prof_on && sel_mode != SEL_FEED_SAMPLE;
+  hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
   if (timed) {
-    hipEvent_t e0, e1;
-    MQ_HIP(hipEventCreate(&e0));
-    MQ_HIP(hipEventCreate(&e1));
-    prof_events.push_back(e0);
-    prof_events.push_back(e1);
-    MQ_HIP(hipEventRecord(e0, st));
+    if (int rc = prof_next_pair(&prof_e0, &prof_e1)) return rc;
+    MQ_HIP(hipEventRecord(prof_e0, st));
   }
   // statistics only: the kernels compiled without the output stores
   const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
@@ -2104,7 +2123,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     default: mq_launch_fmt4(kmode, scope, nv, threads, team_log2, grid, lds, st, b); break;
   }
   MQ_HIP(hipGetLastError());
-  if (timed) MQ_HIP(hipEventRecord(prof_events.back(), st));
+  if (timed) MQ_HIP(hipEventRecord(prof_e1, st));
   if (sel_mode != SEL_FEED_SAMPLE && (o0.totals || (scope == SC_TENSOR && o0.seg_sse))) {
     hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, st, b, (int)grid.x,
                        scope == SC_TENSOR ? 1 : 0);

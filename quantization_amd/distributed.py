@@ -31,7 +31,8 @@ def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tenso
     import torch.distributed as dist
     table = torch.zeros(n_total, width, dtype=torch.float64, device=device)
     if len(local_idx):
-        table[torch.as_tensor(list(local_idx), device=device)] = local_records.to(torch.float64)
+        idx = local_idx if isinstance(local_idx, torch.Tensor) else torch.as_tensor(list(local_idx), device=device)
+        table[idx.to(device)] = local_records.to(torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     return table
@@ -73,18 +74,22 @@ def _bind_select():
 
 
 @torch.no_grad()
-def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=None) -> torch.Tensor:
+def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=None, dtype=None,
+                     total: Optional[int] = None) -> torch.Tensor:
     """np.percentile(np.concatenate(all tensors on all ranks), pct), exact, without moving the data:
     every rank histograms its own tensors, the uint32 histograms are summed with one all-reduce per radix
     level (128 KiB, then 512 KiB per further level), and every rank finishes the same selection.
     All tensors: non-negative, same dtype (float32 or float64), on this rank's device.  A rank may pass
-    an empty list."""
+    an empty list.  dtype / total: the common dtype and the total element count over all ranks when the caller
+    knows them (a sweep repeats the same shapes): then no metadata is exchanged and the host does not wait for
+    the device; otherwise they are agreed on with two small collectives."""
     import torch.distributed as dist
     L = _bind_select()
     dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     dev = torch.device("cuda", torch.cuda.current_device())
-    dtype = tensors[0].dtype if tensors else None
-    if dist_on:
+    known_dtype = dtype is not None
+    dtype = dtype if known_dtype else (tensors[0].dtype if tensors else None)
+    if dist_on and not known_dtype:
         dts = [None] * dist.get_world_size(group)
         dist.all_gather_object(dts, str(dtype) if dtype is not None else None, group=group)
         known = [d for d in dts if d is not None]
@@ -96,10 +101,13 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     code = _lib.F32 if dtype == torch.float32 else 3
     xs = [t.contiguous().reshape(-1) for t in tensors if t.numel()]
     xs = [x.clone() if x.data_ptr() % 16 else x for x in xs]   # (sliced views: the kernels read 16-byte vectors)
-    n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
-    if dist_on:
-        dist.all_reduce(n, group=group)
-    n = int(n.item())
+    if total is None:
+        n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
+        if dist_on:
+            dist.all_reduce(n, group=group)
+        n = int(n.item())
+    else:
+        n = int(total)
     k0, k1, gamma = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_double()
     _lib.check(L.mq_percentile_index(code, n, float(pct), ctypes.byref(k0), ctypes.byref(k1), ctypes.byref(gamma)))
     nbytes = L.mq_percentile_workspace_bytes()

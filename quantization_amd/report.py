@@ -86,7 +86,7 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
 
 @torch.no_grad()
 def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool = True, pct: float = 99.0,
-                  max_err_bytes: int = 8 << 30) -> torch.Tensor:
+                  max_err_bytes: int = 8 << 30, return_vecs: bool = False):
     """layer_record(form="single") for every weight of a model at once: float64 [len(weights), len(RECORD_FIELDS)]
     on the device, nothing synchronised.
 
@@ -94,13 +94,16 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     of quant_weight.py:660-704 fused in: layers are grouped by (shape, dtype) -- a transformer has a handful --
     and every group goes through ONE fused launch per 32 tensors (their pointers, no stacking copy); with
     abs_p99 the P99 of |err| is selected inside that launch.  max_err_bytes bounds the float32 |err| scratch
-    of one launch."""
+    of one launch.  return_vecs: also return the per-vector MSE lists (float64, one per weight, in the order of
+    `weights`) -- what a model-wide percentile over several GPUs is taken from (distributed.joint_percentile)."""
     fmt, table = format_code(datatype)
     weights = list(weights)
     if not weights:
         raise ValueError("model_records() needs at least one weight")
     dev = weights[0].device
     if table in TABLE_LISTS:   # explicit-list tables: layer by layer (their kernel takes one tensor)
+        if return_vecs:
+            raise ValueError("return_vecs is not available for the explicit-list tables")
         return torch.stack([layer_record(w, datatype, bits, group_size, abs_p99=abs_p99) for w in weights])
     out = torch.zeros(len(weights), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
     groups: Dict[Tuple, List[int]] = {}
@@ -138,6 +141,9 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
                                                                                         nan_check=False)
     # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
     out[:, 4] = torch.where(torch.isnan(out[:, 3]), out[:, 3], out[:, 4])
+    if return_vecs:
+        order = {i: k for k, i in enumerate(vec_rows)}
+        return out, [vecs[order[i]] for i in range(len(weights))]
     return out
 
 
