@@ -89,7 +89,7 @@ def algorithmic_bytes_per_elem(in_bytes, lut, asym, gs, outputs):
         b += 2
     if gs and gs > 0:
         per_seg = (2 if outputs.get("scale") else 0) * (2 if asym else 1)
-        per_seg += 8 if outputs.get("seg_sse") else 0
+        per_seg += 8 if outputs.get("seg_sse") else (4 if outputs.get("seg_mse") else 0)
         b += per_seg / gs
     return b
 
@@ -119,10 +119,10 @@ class ModelSweep:
         self.local_elems = sum(sizes[i] for i in self.mine)
         self.total_weight_bytes = sum(sizes) * esz * len(self.passes)          # whole job, every pass counts
         self.local_weight_bytes = self.local_elems * esz * len(self.passes)
-        stats = dict(seg_sse=True)
+        stats = dict(seg_mse=True)
         self.local_algo_bytes = sum(
             sizes[i] * algorithmic_bytes_per_elem(esz, f.startswith("fp"), "asym" in f, gs, stats)
-            + (8 * self.layers[i][1][0] if gs is None else 0)                  # per-row sums of the per-channel passes
+            + (4 * self.layers[i][1][0] if gs is None else 0)                  # per-row MSEs of the per-channel passes
             for i in self.mine for f, _, gs in self.passes)
         self.launches_hint = sum(-(-sum(1 for i in self.mine if self.layers[i][1] == sh) // 32)
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
@@ -158,7 +158,7 @@ class ModelSweep:
         # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
         table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
         # ... and the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists
-        model_p99 = joint_percentile(vecs, 99.0, dtype=torch.float64, total=self.total_vectors)
+        model_p99 = joint_percentile(vecs, 99.0, dtype=torch.float32, total=self.total_vectors, wide=True)
         return table, model_p99
 
 
@@ -190,7 +190,7 @@ class Workload:
         if name == "c2":
             self.desc = (f"c2: 16x 4096x4096 fp16 {dist_name} (scale 0.02), int8-asym g=32/64/128: deq + codes + scale + zp + "
                          "abs-err(f32) dump + per-group/tensor MSE + exact P99 of |err| and of the per-group MSE")
-            outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_sse=True, totals=True)
+            outs = dict(deq=True, codes=True, scale=True, abs_err=torch.float32, seg_mse=True, totals=True)
             g.manual_seed(1000 * rank)
             w = draw((16, 4096, 4096), torch.float16)
             for gs in (32, 64, 128):
@@ -200,7 +200,7 @@ class Workload:
                 shapes, dt = TINYLLAMA * 22 + [(32000, 2048)], torch.float16
             else:   # one GPU's share of the 80 decoder layers (the 561-tensor model split over 8 GPUs)
                 shapes, dt = LLAMA70B * 10, torch.bfloat16
-            stats = dict(deq=False, codes=False, scale=False, abs_err=None, seg_sse=True, totals=True)
+            stats = dict(deq=False, codes=False, scale=False, abs_err=None, seg_mse=True, totals=True)
             if name == "c3":
                 passes = [(_lib.INT_SYM, None, None), (_lib.LUT_FP, "fp8_e4m3", None), (_lib.LUT_FP, "fp8_e3m4", None)]
                 outs = dict(deq=True, codes=False, scale=False, abs_err=None, seg_sse=False, totals=True)
@@ -238,17 +238,14 @@ class Workload:
         self.weight_bytes = sum(w.numel() * w.element_size() for w, *_ in self.batches)
         self.algo_bytes = sum(w.numel() * algorithmic_bytes_per_elem(w.element_size(), f in (_lib.LUT_FP, _lib.LUT_FP_SUB),
                                                                      f == _lib.INT_ASYM, gs, o)
-                              + (8 * w.shape[0] * w.shape[1] if (gs is None and o.get("seg_sse")) else 0)
+                              + (4 * w.shape[0] * w.shape[1] if (gs is None and o.get("seg_mse")) else 0)
                               for w, f, _, gs, o in self.batches)
         self.launches = len(self.batches)
         self.device = device
         self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
-        lens, counts = [], []
+        counts = []
         for w, fmt, dt, gs, outs in self.batches:
-            L = gs if gs else w.shape[2]
-            lens += [L] * w.shape[0]
             counts += [w.shape[1] * w.shape[2]] * w.shape[0]
-        self.post_div = torch.tensor([L if L & (L - 1) == 0 else 1 for L in lens], dtype=torch.float64, device=device)
         self.numel = torch.tensor(counts, dtype=torch.float64, device=device)
         self.totals = torch.zeros(self.tensors, 2, dtype=torch.float64, device=device)
 
@@ -256,7 +253,7 @@ class Workload:
         """All fused quantize launches of the step, then ONE set of select launches per dtype for the P99s of
         every tensor of the step (the chains of short kernels run once per step, not once per batch)."""
         import torch
-        from quantization_amd.error_metrics import percentile_multi, true_div
+        from quantization_amd.error_metrics import percentile_multi
         from quantization_amd.fused import QuantResult, quantize_batch
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
@@ -279,13 +276,13 @@ class Workload:
             rec[:, 0:2] = self.totals
             return rec
         rec[:, 0:2] = self.totals
+        # mean of a tensor's per-vector MSE list = its tensor MSE (all vectors have one length); the P99 is selected
+        # on the float32 list entries and interpolated in float64, as np.percentile of the scripts' float64 list
         rec[:, 2] = self.totals[:, 0] / self.numel
         vecs = []
-        for (w, fmt, dt, gs, outs), res in zip(self.batches, results):
-            L = gs if gs else w.shape[2]
-            per_vec = res.seg_sse if L & (L - 1) == 0 else true_div(res.seg_sse, L)
-            vecs += [per_vec[i] for i in range(per_vec.shape[0])]
-        rec[:, 3] = percentile_multi(vecs, 99, nan_check=False) / self.post_div
+        for res in results:
+            vecs += [res.seg_mse[i] for i in range(res.seg_mse.shape[0])]
+        rec[:, 3] = percentile_multi(vecs, 99, nan_check=False, wide=True)
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
         return rec
@@ -458,7 +455,7 @@ def main():
             out["config"].update({
                 "backend": backend if world > 1 else "none (one rank)",
                 "rccl_ranks": dist.get_world_size() if (world > 1 and backend == "nccl") else 0,
-                "collectives_per_step": "1 all-reduce of the record table + 4 histogram all-reduces (float64 joint P99)"
+                "collectives_per_step": "1 all-reduce of the record table + 2 histogram all-reduces (joint P99 over float32 keys)"
                 if world > 1 else "none",
                 "weight_bytes_per_step_per_rank": [s[0] for s in shares], "layers_per_rank": [s[1] for s in shares]})
 

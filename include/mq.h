@@ -21,7 +21,14 @@
 extern "C" {
 #endif
 
-typedef enum { MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2, MQ_F64 = 3 } mq_dtype;
+typedef enum {
+  MQ_F16 = 0, MQ_BF16 = 1, MQ_F32 = 2, MQ_F64 = 3,
+  MQ_F32_AS_F64 = 4 /* percentile functions only: a float32 array standing for the float64 array that holds the same
+                       values -- vec = np.array(per_vec) of float(np.float32) means in the analysis scripts
+                       (quant_error_single_weight.py:46-48, :74-79): the selection runs on the float32 bits (two
+                       passes), ranks, interpolation and results are float64, bit for bit what np.percentile
+                       returns for the float64 array */
+} mq_dtype;
 
 /* Quantization formats of the hot path. */
 typedef enum {
@@ -68,7 +75,9 @@ typedef struct {
   void* zero_point;      /* float16 [nseg], INT_ASYM only */
   void* abs_err;         /* |float16(w) - deq| per element, float32 or float16 [rows*cols]          */
   int32_t abs_err_dtype; /* MQ_F32: onnx_error_cli.py:90-91;  MQ_F16: single_weight_quant_error.py:39-40 */
-  int32_t reserved;
+  int32_t seg_mse_f32;   /* 0: seg_sse receives float64 sums; 1: seg_sse points to a float32 [nseg] array that
+                            receives each segment's mean squared error, float32(sum * (1 / length)): the list
+                            entry compute_mse returns, a float32 np.mean (quant_error_single_weight.py:46-48) */
   double* seg_sse;       /* float64 [nseg] sum of squared float32 errors per segment (row form,
                             quant_error_single_weight.py:56-71 before the division by the length)  */
   double* totals;        /* float64 [2]: sum of squared errors, sum of absolute errors (float32 errors,
@@ -202,7 +211,8 @@ size_t mq_percentile_workspace_bytes(void);
  *                               (float64 per-vector MSE list)
  * The virtual index, its floor and the interpolation follow numpy 2.2 in the array's dtype, so the result
  * has the same bits as numpy's.  out (one value) and out_pair (the two order statistics interpolated
- * between) are device pointers of the array's dtype; either may be NULL.  x must be 16-byte aligned.
+ * between) are device pointers of the array's dtype (float64 for MQ_F32_AS_F64); either may be NULL.  x must
+ * be 16-byte aligned.  Every percentile / select function below takes the same three dtype codes.
  */
 int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct, void* out, void* out_pair,
                   void* workspace, size_t workspace_bytes, void* hip_stream);
@@ -233,6 +243,9 @@ int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t* k0, int64
 int mq_select_begin(void* workspace, size_t workspace_bytes, void* hip_stream);
 int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
                          size_t workspace_bytes, void* hip_stream);
+/* mq_select_accumulate for `count` arrays (xs, ns: HOST arrays of device pointers / lengths), 64 per launch. */
+int mq_select_accumulate_multi(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype, int32_t level,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
 int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t finish, int32_t dtype, double gamma, void* out,
                    void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmq.so")
 
-F16, BF16, F32 = 0, 1, 2
+F16, BF16, F32, F64, F32_AS_F64 = 0, 1, 2, 3, 4
 INT_SYM, INT_ASYM, LUT_FP, LUT_FP_SUB = 0, 1, 2, 3
 TABLE_F16, TABLE_F32, TABLE_MX = 0, 1, 2
 TABLE_MAX_VALUES = 256
@@ -27,7 +27,7 @@ class QuantCfg(ctypes.Structure):
 class QuantOut(ctypes.Structure):
     _fields_ = [("deq", ctypes.c_void_p), ("codes", ctypes.c_void_p), ("scale", ctypes.c_void_p),
                 ("zero_point", ctypes.c_void_p), ("abs_err", ctypes.c_void_p), ("abs_err_dtype", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("seg_sse", ctypes.c_void_p), ("totals", ctypes.c_void_p)]
+                ("seg_mse_f32", ctypes.c_int32), ("seg_sse", ctypes.c_void_p), ("totals", ctypes.c_void_p)]
 
 
 class TableCfg(ctypes.Structure):

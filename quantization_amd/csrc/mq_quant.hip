@@ -77,6 +77,8 @@ struct QuantParams {
   void* abs_err;
   int32_t abs_err_f16;
   double* seg_sse;
+  double seg_mse_scale;  // 0: seg_sse receives float64 sums; 1 / L: seg_sse points to float32 words that receive
+                         // the segment's mean squared error float32(sum * (1 / L))
   double* partials;      // [gridDim.x][2]
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
   int32_t sel_mode;      // SEL_FEED_*: feed the float32 |error| values to a percentile selection
@@ -125,6 +127,11 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
   p.sel_ws = p.sel_mode ? reinterpret_cast<SelWs*>(b.sel_ws + (int64_t)blockIdx.y * sizeof(SelWs)) : nullptr;
   p.sel_samples = p.sel_mode ? b.common.sel_samples + (int64_t)blockIdx.y * b.sample_stride : nullptr;
   return p;
+}
+
+__device__ __forceinline__ void store_seg(const QuantParams& p, int64_t seg, double sum) {
+  if (p.seg_mse_scale != 0.0) reinterpret_cast<float*>(p.seg_sse)[seg] = (float)(sum * p.seg_mse_scale);
+  else p.seg_sse[seg] = sum;
 }
 
 struct SegP {
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
       acc_sse += s;
       if (p.seg_sse) {
         s = team_sum<T>(s);
-        if (valid[j] && tl == 0) p.seg_sse[seg[j]] = s;
+        if (valid[j] && tl == 0) store_seg(p, seg[j], s);
       }
       if (valid[j] && tl == 0) {
         if (p.scale) p.scale[seg[j]] = (uint16_t)h_bits(sp.s);
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(256) void k_quant_team4(const QuantBatch b) {
     acc_sse += s;
     if (p.seg_sse) {
       s = team_sum<T>(s);
-      if (valid && tl == 0) p.seg_sse[seg] = s;
+      if (valid && tl == 0) store_seg(p, seg, s);
     }
     if (valid && tl == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
@@ -1058,10 +1065,10 @@ __device__ __forceinline__ void row_body(const QuantParams& p, double* lds, doub
         if (threadIdx.x == 0) {
           double t = 0.0;
           for (int i = 0; i < nw; ++i) t += ex[i];
-          p.seg_sse[seg] = t;
+          store_seg(p, seg, t);
         }
       } else if (lane == 0) {
-        p.seg_sse[seg] = s;
+        store_seg(p, seg, s);
       }
     }
     if (tid == 0) {
@@ -1259,7 +1266,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     acc_abs += take ? ab : 0.0;
     if (p.seg_sse) {
       s = team_sum<T>(s);
-      if (valid && tl == 0) p.seg_sse[seg] = s;
+      if (valid && tl == 0) store_seg(p, seg, s);
     }
     if (valid && tl == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
@@ -1378,10 +1385,10 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const Quan
           double t = 0.0;
 #pragma unroll
           for (int i = 0; i < WPR; ++i) t += xs[parity][i];
-          p.seg_sse[row] = t;
+          store_seg(p, row, t);
         }
       } else if (lane == 0) {
-        p.seg_sse[row] = s;
+        store_seg(p, row, s);
       }
     }
     if (lane == 0 && sub == 0) {
@@ -1641,7 +1648,7 @@ __global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
       if (threadIdx.x == 0) {
         double t = 0.0;
         for (int i = 0; i < nw; ++i) t += ex[i];
-        p.seg_sse[seg] = t;
+        store_seg(p, seg, t);
       }
     }
     if (threadIdx.x == 0) {
@@ -1671,7 +1678,10 @@ __global__ __launch_bounds__(256) void k_finalize_totals(const QuantBatch b, int
     double x = 0.0, y = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { x += lds[i]; y += lds[16 + i]; }
     if (it.totals) { it.totals[0] = x; it.totals[1] = y; }
-    if (tensor_scope && it.seg_sse) it.seg_sse[0] = x;
+    if (tensor_scope && it.seg_sse) {
+      if (b.common.seg_mse_scale != 0.0) reinterpret_cast<float*>(it.seg_sse)[0] = (float)(x * b.common.seg_mse_scale);
+      else it.seg_sse[0] = x;
+    }
   }
 }
 
@@ -1982,6 +1992,8 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   if (o0.abs_err && o0.abs_err_dtype != MQ_F32 && o0.abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
   p.abs_err_f16 = o0.abs_err_dtype == MQ_F16;
   p.need_err = (o0.abs_err || o0.seg_sse || o0.totals) ? 1 : 0;
+  if (o0.seg_mse_f32 != 0 && o0.seg_mse_f32 != 1) return MQ_ERR_ARG;
+  p.seg_mse_scale = (o0.seg_sse && o0.seg_mse_f32) ? 1.0 / (double)p.L : 0.0;
   p.tred = static_cast<const uint32_t*>(workspace);
   b.ws_stride = (int64_t)ws_slice_bytes();
   const size_t esz = w_dtype == MQ_F32 ? 4 : 2;
@@ -1991,10 +2003,11 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     if (!items[i].w) return MQ_ERR_ARG;
     if (!o.deq != !o0.deq || !o.codes != !o0.codes || !o.scale != !o0.scale || !o.zero_point != !o0.zero_point ||
         !o.abs_err != !o0.abs_err || !o.seg_sse != !o0.seg_sse || !o.totals != !o0.totals ||
-        (o.abs_err && o.abs_err_dtype != o0.abs_err_dtype))
+        (o.abs_err && o.abs_err_dtype != o0.abs_err_dtype) || o.seg_mse_f32 != o0.seg_mse_f32)
       return MQ_ERR_ARG;
     if (!aligned(items[i].w, esz) || !aligned(o.deq, 2) || !aligned(o.scale, 2) || !aligned(o.zero_point, 2) ||
-        !aligned(o.seg_sse, 8) || !aligned(o.totals, 8) || !aligned(o.abs_err, p.abs_err_f16 ? 2 : 4) ||
+        !aligned(o.seg_sse, o.seg_mse_f32 ? 4 : 8) || !aligned(o.totals, 8) ||
+        !aligned(o.abs_err, p.abs_err_f16 ? 2 : 4) ||
         (MQ_IS_LUT(fmt) && !aligned(o.codes, 2)))
       return MQ_ERR_ALIGN;
     vec_ok = vec_ok && aligned(items[i].w, 16) && aligned(o.deq, 16) && aligned(o.codes, 16) && aligned(o.abs_err, 16);

@@ -112,10 +112,33 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
 // (lib/_function_base_impl.py::_lerp) in that dtype:
 //   r = a + (b - a) * t;  where t >= 0.5:  r = b - (b - a) * (1 - t)
 struct FinishArgs {
-  int32_t dtype;  // -1: no finish here; MQ_F32 / MQ_F64
+  int32_t dtype;  // -1: no finish here; MQ_F32 / MQ_F64 / MQ_F32_AS_F64
   char* out;       // [batch] values of dtype
   char* out_pair;  // [batch][2]
 };
+
+// numpy's interpolation between the two order statistics (lib/_function_base_impl.py::_lerp) and the stores.
+// p0 / p1: the located keys (float32 bits in the high word, or float64 bits).  MQ_F32_AS_F64: float32 keys, but
+// the array they stand for is float64: widen first, interpolate and store in float64.
+__device__ __forceinline__ void finish_store(const FinishArgs& fin, int idx, uint64_t p0, uint64_t p1, double gamma) {
+  if (fin.dtype == MQ_F32) {
+    float a = f_from_bits((uint32_t)(p0 >> 32)), c = f_from_bits((uint32_t)(p1 >> 32));
+    float g = (float)gamma, diff = c - a;
+    float v = a + diff * g;
+    if (g >= 0.5f) v = c - diff * (1.0f - g);
+    if (fin.out) reinterpret_cast<float*>(fin.out)[idx] = v;
+    if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * idx] = a; reinterpret_cast<float*>(fin.out_pair)[2 * idx + 1] = c; }
+  } else if (fin.dtype == MQ_F64 || fin.dtype == MQ_F32_AS_F64) {
+    const bool wide = fin.dtype == MQ_F32_AS_F64;
+    double a = wide ? (double)f_from_bits((uint32_t)(p0 >> 32)) : __builtin_bit_cast(double, p0);
+    double c = wide ? (double)f_from_bits((uint32_t)(p1 >> 32)) : __builtin_bit_cast(double, p1);
+    double g = gamma, diff = c - a;
+    double v = a + diff * g;
+    if (g >= 0.5) v = c - diff * (1.0 - g);
+    if (fin.out) reinterpret_cast<double*>(fin.out)[idx] = v;
+    if (fin.out_pair) { reinterpret_cast<double*>(fin.out_pair)[2 * idx] = a; reinterpret_cast<double*>(fin.out_pair)[2 * idx + 1] = c; }
+  }
+}
 
 // Inclusive block scan of one value per thread (256 threads); returns the exclusive prefix of this thread.
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t v, uint64_t* wsum /*[4]*/) {
@@ -171,12 +194,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
           while (d + 1 < width && rest >= ws->refine[r][d]) { rest -= ws->refine[r][d]; ++d; }
           bits[r] = ws->ref_base[r] + d;
         }
-        float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
-        float g = (float)rk.gamma[blockIdx.x], diff = c - a;
-        float v = a + diff * g;
-        if (g >= 0.5f) v = c - diff * (1.0f - g);
-        if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
-        if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+        finish_store(fin, blockIdx.x, (uint64_t)bits[0] << 32, (uint64_t)bits[1] << 32, rk.gamma[blockIdx.x]);
         ws->st.prefix[0] = (uint64_t)bits[0] << 32;
         ws->st.prefix[1] = (uint64_t)bits[1] << 32;
         ws->ok = 1;
@@ -212,21 +230,7 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
   if (threadIdx.x == 0) {
     res.same = res.prefix[0] == res.prefix[1] ? 1 : 0;
     ws->st = res;
-    if (fin.dtype == MQ_F32) {
-      float a = f_from_bits((uint32_t)(res.prefix[0] >> 32)), c = f_from_bits((uint32_t)(res.prefix[1] >> 32));
-      float g = (float)rk.gamma[blockIdx.x], diff = c - a;
-      float v = a + diff * g;
-      if (g >= 0.5f) v = c - diff * (1.0f - g);
-      if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
-      if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
-    } else if (fin.dtype == MQ_F64) {
-      double a = __builtin_bit_cast(double, res.prefix[0]), c = __builtin_bit_cast(double, res.prefix[1]);
-      double g = rk.gamma[blockIdx.x], diff = c - a;
-      double v = a + diff * g;
-      if (g >= 0.5) v = c - diff * (1.0 - g);
-      if (fin.out) reinterpret_cast<double*>(fin.out)[blockIdx.x] = v;
-      if (fin.out_pair) { reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
-    }
+    finish_store(fin, blockIdx.x, res.prefix[0], res.prefix[1], rk.gamma[blockIdx.x]);
   }
 }
 
@@ -296,23 +300,7 @@ __global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelR
     }
     remaining -= width;
   }
-  if (threadIdx.x == 0) {
-    if (fin.dtype == MQ_F32) {
-      float a = f_from_bits((uint32_t)(s_prefix[0] >> 32)), c = f_from_bits((uint32_t)(s_prefix[1] >> 32));
-      float g = (float)rk.gamma[blockIdx.x], diff = c - a;
-      float v = a + diff * g;
-      if (g >= 0.5f) v = c - diff * (1.0f - g);
-      if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
-      if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
-    } else {
-      double a = __builtin_bit_cast(double, s_prefix[0]), c = __builtin_bit_cast(double, s_prefix[1]);
-      double g = rk.gamma[blockIdx.x], diff = c - a;
-      double v = a + diff * g;
-      if (g >= 0.5) v = c - diff * (1.0 - g);
-      if (fin.out) reinterpret_cast<double*>(fin.out)[blockIdx.x] = v;
-      if (fin.out_pair) { reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<double*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
-    }
-  }
+  if (threadIdx.x == 0) finish_store(fin, blockIdx.x, s_prefix[0], s_prefix[1], rk.gamma[blockIdx.x]);
 }
 
 // ---- levels 1..3 -----------------------------------------------------------------------------------
@@ -645,12 +633,7 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
       ws->ok = 2;
       return;
     }
-    float a = f_from_bits(bits[0]), c = f_from_bits(bits[1]);
-    float g = (float)rk.gamma[blockIdx.x], diff = c - a;
-    float v = a + diff * g;
-    if (g >= 0.5f) v = c - diff * (1.0f - g);
-    if (fin.out) reinterpret_cast<float*>(fin.out)[blockIdx.x] = v;
-    if (fin.out_pair) { reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x] = a; reinterpret_cast<float*>(fin.out_pair)[2 * blockIdx.x + 1] = c; }
+    finish_store(fin, blockIdx.x, (uint64_t)bits[0] << 32, (uint64_t)bits[1] << 32, rk.gamma[blockIdx.x]);
     ws->st.prefix[0] = (uint64_t)bits[0] << 32;
     ws->st.prefix[1] = (uint64_t)bits[1] << 32;
     ws->ok = 1;
@@ -658,8 +641,11 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
 }
 
 // ================================================================================================
+// MQ_F32_AS_F64 selects among float32 keys; only the ranks, the interpolation and the results are float64.
+static bool f32_keys(int32_t dtype) { return dtype == MQ_F32 || dtype == MQ_F32_AS_F64; }
+static bool sel_dtype_ok(int32_t dtype) { return dtype == MQ_F32 || dtype == MQ_F64 || dtype == MQ_F32_AS_F64; }
 static size_t ws_used_bytes(int32_t dtype) {  // what one selection of this dtype touches
-  return offsetof(SelWs, lvl) + (size_t)(dtype == MQ_F32 ? 1 : 3) * sizeof(SelLevel);
+  return offsetof(SelWs, lvl) + (size_t)(f32_keys(dtype) ? 1 : 3) * sizeof(SelLevel);
 }
 extern "C" size_t mq_percentile_workspace_bytes(void) { return sizeof(SelWs); }
 extern "C" size_t mq_percentile_batch_workspace_bytes(int32_t count) {
@@ -691,7 +677,7 @@ extern "C" int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t
     *gamma = (double)(vi - prev);
     *k0 = (int64_t)prev;
     if (vi >= (float)(n - 1)) *k0 = n - 1;
-  } else if (dtype == MQ_F64) {
+  } else if (dtype == MQ_F64 || dtype == MQ_F32_AS_F64) {
     double q = pct / 100.0;
     double vi = (double)(n - 1) * q;
     double prev = __builtin_floor(vi);
@@ -726,12 +712,12 @@ static bool bracket_ranks(int64_t n, int64_t k0, int64_t k1, int64_t* m_out, dou
 
 static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t dtype, int level, hipStream_t st,
                              int guard = 0) {
-  const int V = dtype == MQ_F32 ? 4 : 2;
+  const int V = f32_keys(dtype) ? 4 : 2;
   if (level == 0) {
     int64_t nb = (nmax / V + 1024 * 4 - 1) / (1024 * 4);
     int64_t cap = 256 / count < 4 ? 4 : 256 / count;  // one 128 KiB-LDS workgroup fits per CU
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
-    if (dtype == MQ_F32) {
+    if (f32_keys(dtype)) {
       MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<float>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
       hipLaunchKernelGGL((k_sel_hist_top<float>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
@@ -744,7 +730,7 @@ static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t
     int64_t nb = (nmax / V + 256 * 4 - 1) / (256 * 4);
     int64_t cap = 1024 / count < 16 ? 16 : 1024 / count;
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
-    if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_hist_digit<float>), grid, dim3(256), 0, st, b, level, guard);
+    if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_hist_digit<float>), grid, dim3(256), 0, st, b, level, guard);
     else hipLaunchKernelGGL((k_sel_hist_digit<double>), grid, dim3(256), 0, st, b, level, guard);
   }
   MQ_HIP(hipGetLastError());
@@ -762,7 +748,7 @@ extern "C" int mq_select_begin(void* workspace, size_t workspace_bytes, void* hi
 // May be called for several arrays before the scan.
 extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int32_t level, void* workspace,
                                     size_t workspace_bytes, void* hip_stream) {
-  if (n < 0 || (n > 0 && !x) || (dtype != MQ_F32 && dtype != MQ_F64) || level < 0 || level > 3) return MQ_ERR_ARG;
+  if (n < 0 || (n > 0 && !x) || !sel_dtype_ok(dtype) || level < 0 || level > 3) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
   if (!al16(x) || !al16(workspace)) return MQ_ERR_ALIGN;
   if (n == 0) return MQ_OK;
@@ -773,6 +759,39 @@ extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int
   return launch_accumulate(b, 1, n, dtype, level, static_cast<hipStream_t>(hip_stream));
 }
 
+// The same for `count` arrays at once (xs, ns: HOST arrays): one launch per 64 arrays, all adding into the one
+// selection of `workspace`.  A model-wide percentile over hundreds of short per-layer lists is otherwise a chain
+// of launches that each clear and flush a whole histogram for a few thousand values.
+extern "C" int mq_select_accumulate_multi(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype,
+                                          int32_t level, void* workspace, size_t workspace_bytes, void* hip_stream) {
+  if (count < 0 || (count > 0 && (!xs || !ns)) || !sel_dtype_ok(dtype) || level < 0 || level > 3) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
+  if (!al16(workspace)) return MQ_ERR_ALIGN;
+  for (int i = 0; i < count; ++i) {
+    if (ns[i] < 0 || (ns[i] > 0 && !xs[i])) return MQ_ERR_ARG;
+    if (!al16(xs[i])) return MQ_ERR_ALIGN;
+  }
+  int done = 0;
+  while (done < count) {
+    SelBatch b = {};
+    int c = 0;
+    int64_t nmax = 0;
+    for (; done < count && c < SEL_MAX_BATCH; ++done) {
+      if (ns[done] == 0) continue;
+      b.x[c] = xs[done];
+      b.n[c] = ns[done];
+      nmax = ns[done] > nmax ? ns[done] : nmax;
+      ++c;
+    }
+    if (c == 0) break;
+    b.ws = static_cast<char*>(workspace);
+    b.ws_stride = 0;  // every array of the launch adds into the same histograms
+    int rc = launch_accumulate(b, c, nmax, dtype, level, static_cast<hipStream_t>(hip_stream));
+    if (rc) return rc;
+  }
+  return MQ_OK;
+}
+
 // Step 3 / 5: locate the ranks in the (merged) histogram of `level` and extend the prefixes.  The ranks
 // k0 <= k1 are read at level 0.  With finish != 0 (pass it at the last level: 1 for float32, 3 for
 // float64) the two order statistics and numpy's interpolation between them are written, in `dtype`, to
@@ -780,7 +799,7 @@ extern "C" int mq_select_accumulate(const void* x, int32_t dtype, int64_t n, int
 extern "C" int mq_select_scan(int32_t level, int64_t k0, int64_t k1, int32_t finish, int32_t dtype, double gamma,
                               void* out, void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream) {
   if (level < 0 || level > 3 || (level == 0 && (k0 < 0 || k1 < k0))) return MQ_ERR_ARG;
-  if (finish && dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
+  if (finish && !sel_dtype_ok(dtype)) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < sizeof(SelWs)) return MQ_ERR_WORKSPACE;
   SelBatch b = {};
   b.ws = static_cast<char*>(workspace);
@@ -821,7 +840,7 @@ static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t
   }
   b.ws = static_cast<char*>(workspace);
   b.ws_stride = (int64_t)sizeof(SelWs);
-  const int levels = dtype == MQ_F32 ? 1 : 3;
+  const int levels = f32_keys(dtype) ? 1 : 3;
   // clear what this selection accumulates into: header + level histograms, and the sample area
   const uint32_t a_end = (uint32_t)ws_used_bytes(dtype);
   const uint32_t b_begin = bracket ? (uint32_t)offsetof(SelWs, samp_coarse) : 0u;
@@ -872,7 +891,7 @@ static int select_small(const void* const* xs, const int64_t* ns, int c, int32_t
     rk.k1[i] = (uint64_t)k1;
   }
   FinishArgs fin = {dtype, out, out_pair};
-  if (dtype == MQ_F32) hipLaunchKernelGGL((k_sel_small<float>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+  if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_small<float>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
   else hipLaunchKernelGGL((k_sel_small<double>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
@@ -887,7 +906,7 @@ extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int
                                    void* out, void* out_pair, void* workspace, size_t workspace_bytes,
                                    void* hip_stream) {
   if (count < 0 || (count > 0 && (!xs || !ns)) || (!out && !out_pair)) return MQ_ERR_ARG;
-  if (dtype != MQ_F32 && dtype != MQ_F64) return MQ_ERR_ARG;
+  if (!sel_dtype_ok(dtype)) return MQ_ERR_ARG;
   if (count == 0) return MQ_OK;
   if (!workspace || workspace_bytes < mq_percentile_batch_workspace_bytes(count > SEL_MAX_BATCH ? SEL_MAX_BATCH : count))
     return MQ_ERR_WORKSPACE;
@@ -897,7 +916,7 @@ extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int
     if (!al16(xs[i])) return MQ_ERR_ALIGN;
   }
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
-  const size_t esz = dtype == MQ_F32 ? 4 : 8;
+  const size_t esz = dtype == MQ_F32 ? 4 : 8;  // of the results
   // consecutive arrays that take the same route form a group
   // 0: exact multi-launch route, 1: sample + bracket in front of it, 2: short array, one launch
   auto route = [&](int i) {
@@ -905,7 +924,7 @@ extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int
     double g, lo, hi;
     if (ns[i] <= SEL_SMALL_N) return 2;
     if (mq_percentile_index(dtype, ns[i], pct, &k0, &k1, &g)) return 0;
-    return dtype == MQ_F32 && bracket_ranks(ns[i], k0, k1, &m, &lo, &hi) ? 1 : 0;
+    return f32_keys(dtype) && bracket_ranks(ns[i], k0, k1, &m, &lo, &hi) ? 1 : 0;
   };
   int done = 0;
   while (done < count) {

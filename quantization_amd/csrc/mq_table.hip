@@ -28,6 +28,7 @@ struct TableParams {
   void* scale;
   void* abs_err;
   double* seg_sse;
+  double seg_mse_scale;  // 0: float64 sums; 1 / L: seg_sse points to float32 MSEs (mq_quant_out.seg_mse_f32)
   double* partials;  // [gridDim.x][2]
   uint32_t* tred;    // per-tensor scope: max over the |value| bits
   float vals[MQ_TABLE_MAX_VALUES];
@@ -218,7 +219,10 @@ __global__ __launch_bounds__(256) void k_table_seg(const TableParams p) {
         __syncthreads();
         s = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
       }
-      if (tid == 0) p.seg_sse[seg] = s;
+      if (tid == 0) {
+        if (p.seg_mse_scale != 0.0) reinterpret_cast<float*>(p.seg_sse)[seg] = (float)(s * p.seg_mse_scale);
+        else p.seg_sse[seg] = s;
+      }
     }
     if (tid == 0) tbl_store_scale(p, sp, seg);
   }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void k_table_flat(const TableParams p) {
 }
 
 __global__ __launch_bounds__(256) void k_table_finalize(const double* partials, int nblocks, double* totals,
-                                                        double* seg_sse0) {
+                                                        double* seg_sse0, double seg_mse_scale) {
   __shared__ double lds[32];
   double a = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += partials[2 * i]; c += partials[2 * i + 1]; }
@@ -269,7 +273,10 @@ __global__ __launch_bounds__(256) void k_table_finalize(const double* partials, 
     double x = 0.0, y = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { x += lds[i]; y += lds[16 + i]; }
     if (totals) { totals[0] = x; totals[1] = y; }
-    if (seg_sse0) seg_sse0[0] = x;
+    if (seg_sse0) {
+      if (seg_mse_scale != 0.0) reinterpret_cast<float*>(seg_sse0)[0] = (float)(x * seg_mse_scale);
+      else seg_sse0[0] = x;
+    }
   }
 }
 
@@ -307,7 +314,7 @@ static int table_launch(const TableParams& p, bool per_tensor, const mq_quant_ou
   MQ_HIP(hipGetLastError());
   if (out->totals || (per_tensor && out->seg_sse)) {
     hipLaunchKernelGGL(k_table_finalize, dim3(1), dim3(256), 0, st, p.partials, (int)blocks, out->totals,
-                       per_tensor ? out->seg_sse : nullptr);
+                       per_tensor ? out->seg_sse : nullptr, p.seg_mse_scale);
     MQ_HIP(hipGetLastError());
   }
   return MQ_OK;
@@ -341,12 +348,13 @@ extern "C" int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, i
   if (n == 0) return MQ_OK;
   if (!w) return MQ_ERR_ARG;
   if (out->abs_err && out->abs_err_dtype != MQ_F32 && out->abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
+  if (out->seg_mse_f32 != 0 && out->seg_mse_f32 != 1) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < mq_quantize_table_workspace_bytes(rows, cols, cfg)) return MQ_ERR_WORKSPACE;
   const size_t wide = cfg->math == MQ_TABLE_F16 ? 2 : 4;  // element size of codes / scale
   if (!tbl_aligned(workspace, 16) || !tbl_aligned(w, w_dtype == MQ_F32 ? 4 : 2) ||
       !tbl_aligned(out->deq, cfg->deq_dtype == MQ_F32 ? 4 : 2) || !tbl_aligned(out->codes, wide) ||
       !tbl_aligned(out->scale, wide) || !tbl_aligned(out->abs_err, out->abs_err_dtype == MQ_F16 ? 2 : 4) ||
-      !tbl_aligned(out->seg_sse, 8) || !tbl_aligned(out->totals, 8))
+      !tbl_aligned(out->seg_sse, out->seg_mse_f32 ? 4 : 8) || !tbl_aligned(out->totals, 8))
     return MQ_ERR_ALIGN;
 
   TableParams p = {};
@@ -368,6 +376,7 @@ extern "C" int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, i
   p.scale = out->scale;
   p.abs_err = out->abs_err;
   p.seg_sse = out->seg_sse;
+  p.seg_mse_scale = (out->seg_sse && out->seg_mse_f32) ? 1.0 / (double)p.L : 0.0;
   p.tred = static_cast<uint32_t*>(workspace);
   p.partials = (out->totals || (cfg->group_size == -1 && out->seg_sse))
                    ? reinterpret_cast<double*>(static_cast<char*>(workspace) + kTblHeader)

@@ -67,6 +67,8 @@ def _bind_select():
     L.mq_select_begin.argtypes = [vp, sz, vp]
     L.mq_select_accumulate.restype = ctypes.c_int
     L.mq_select_accumulate.argtypes = [vp, i32, i64, i32, vp, sz, vp]
+    L.mq_select_accumulate_multi.restype = ctypes.c_int
+    L.mq_select_accumulate_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, i32, vp, sz, vp]
     L.mq_select_scan.restype = ctypes.c_int
     L.mq_select_scan.argtypes = [i32, i64, i64, i32, i32, dbl, vp, vp, vp, sz, vp]
     L._sel_bound = True
@@ -75,14 +77,17 @@ def _bind_select():
 
 @torch.no_grad()
 def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=None, dtype=None,
-                     total: Optional[int] = None) -> torch.Tensor:
+                     total: Optional[int] = None, wide: bool = False) -> torch.Tensor:
     """np.percentile(np.concatenate(all tensors on all ranks), pct), exact, without moving the data:
     every rank histograms its own tensors, the uint32 histograms are summed with one all-reduce per radix
     level (128 KiB, then 512 KiB per further level), and every rank finishes the same selection.
     All tensors: non-negative, same dtype (float32 or float64), on this rank's device.  A rank may pass
     an empty list.  dtype / total: the common dtype and the total element count over all ranks when the caller
     knows them (a sweep repeats the same shapes): then no metadata is exchanged and the host does not wait for
-    the device; otherwise they are agreed on with two small collectives."""
+    the device; otherwise they are agreed on with two small collectives.  wide (float32 tensors): the result
+    is np.percentile of the float64 array holding the same values (float32 keys: two histogram levels; float64
+    ranks, interpolation and result) -- per-vector MSE lists are float32 means kept in a float64 array by the
+    analysis scripts (quant_error_single_weight.py:74-79)."""
     import torch.distributed as dist
     L = _bind_select()
     dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -98,7 +103,9 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
         dtype = {"torch.float32": torch.float32, "torch.float64": torch.float64}[known[0]]
     if dtype not in (torch.float32, torch.float64):
         raise ValueError("float32 or float64 tensors expected")
-    code = _lib.F32 if dtype == torch.float32 else 3
+    if wide and dtype != torch.float32:
+        raise ValueError("wide=True takes float32 tensors")
+    code = _lib.F32_AS_F64 if wide else (_lib.F32 if dtype == torch.float32 else _lib.F64)
     xs = [t.contiguous().reshape(-1) for t in tensors if t.numel()]
     xs = [x.clone() if x.data_ptr() % 16 else x for x in xs]   # (sliced views: the kernels read 16-byte vectors)
     if total is None:
@@ -114,12 +121,13 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream(dev).cuda_stream
     wp, wn = ws.data_ptr(), ws.numel()
-    out = torch.empty((), dtype=dtype, device=dev)
+    out = torch.empty((), dtype=torch.float64 if wide else dtype, device=dev)
     _lib.check(L.mq_select_begin(wp, wn, st))
     levels = 1 if dtype == torch.float32 else 3
+    ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    lens = (ctypes.c_int64 * len(xs))(*[x.numel() for x in xs])
     for level in range(levels + 1):
-        for x in xs:
-            _lib.check(L.mq_select_accumulate(x.data_ptr(), code, x.numel(), level, wp, wn, st))
+        _lib.check(L.mq_select_accumulate_multi(ptrs, lens, len(xs), code, level, wp, wn, st))
         if dist_on:
             off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
             L.mq_select_layout(level, ctypes.byref(off), ctypes.byref(cnt))

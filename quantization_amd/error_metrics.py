@@ -16,7 +16,17 @@ import torch
 from . import _lib
 from .fused import require_device, workspace
 
-_DT = {torch.float16: _lib.F16, torch.float32: _lib.F32, torch.float64: 3}
+_DT = {torch.float16: _lib.F16, torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _sel_dtype(dtype, wide):
+    """(dtype code, result dtype) of a selection.  wide: float32 values standing for the float64 array that
+    holds them (a list of float32 means turned into np.array(...)): float32 keys, float64 ranks and results."""
+    if wide:
+        if dtype != torch.float32:
+            raise ValueError("wide=True takes float32 tensors")
+        return _lib.F32_AS_F64, torch.float64
+    return _DT[dtype], dtype
 
 
 def _bind():
@@ -56,26 +66,29 @@ def _ptr(t):
 
 
 @torch.no_grad()
-def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False, nan_check: bool = True):
+def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False, nan_check: bool = True,
+               wide: bool = False):
     """np.percentile(x, pct) (method 'linear') of a non-negative float32 / float64 device tensor, exact:
     two-pass (float32) or four-pass (float64) radix select on the bit patterns.  Returns a 0-d device
     tensor of x's dtype (and the two interpolated order statistics when return_pair).  nan_check: one more pass
     over x that turns the result into NaN when x holds one, as numpy does (without it a NaN counts as the
-    largest value)."""
+    largest value).  wide (float32 x): np.percentile(x.astype(np.float64), pct) -- the same two passes over the
+    float32 bits, ranks / interpolation / result in float64."""
     x = require_device(x)
     if x.dtype not in (torch.float32, torch.float64):
         raise ValueError("percentile() takes float32 or float64")
+    code, rdt = _sel_dtype(x.dtype, wide)
     x = x.contiguous().reshape(-1)
     if x.numel() == 0:
         raise IndexError("percentile of an empty array")
     if x.data_ptr() % 16:
         x = x.clone()   # (a sliced view: the kernels read 16-byte vectors)
     L = _bind()
-    out = torch.empty((), dtype=x.dtype, device=x.device)
-    pair = torch.empty(2, dtype=x.dtype, device=x.device) if return_pair else None
+    out = torch.empty((), dtype=rdt, device=x.device)
+    pair = torch.empty(2, dtype=rdt, device=x.device) if return_pair else None
     with torch.cuda.device(x.device):
         ws, stream = workspace(x.device, L.mq_percentile_workspace_bytes())
-        st = L.mq_percentile(x.data_ptr(), _DT[x.dtype], x.numel(), float(pct), out.data_ptr(), _ptr(pair),
+        st = L.mq_percentile(x.data_ptr(), code, x.numel(), float(pct), out.data_ptr(), _ptr(pair),
                              ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     if nan_check:
@@ -85,9 +98,10 @@ def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False, na
 
 
 @torch.no_grad()
-def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
+def percentile_batch(x: torch.Tensor, pct: float = 99.0, wide: bool = False) -> torch.Tensor:
     """np.percentile(x[i], pct) for every row of a [B, n] float32 / float64 device tensor (rows must be
-    contiguous and 16-byte aligned: n * itemsize % 16 == 0, or B == 1); one set of launches for all rows."""
+    contiguous and 16-byte aligned: n * itemsize % 16 == 0, or B == 1); one set of launches for all rows.
+    wide: as for percentile()."""
     x = require_device(x)
     if x.dtype not in (torch.float32, torch.float64) or x.dim() != 2:
         raise ValueError("percentile_batch() takes a 2-D float32 or float64 tensor")
@@ -96,15 +110,16 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
     if n == 0:
         raise IndexError("percentile of an empty array")
     if (n * x.element_size()) % 16 and B > 1:
-        return torch.stack([percentile(x[i], pct) for i in range(B)])
+        return torch.stack([percentile(x[i], pct, wide=wide) for i in range(B)])
+    code, rdt = _sel_dtype(x.dtype, wide)
     L = _bind()
     if x.data_ptr() % 16:
         x = x.clone()
-    out = torch.empty(B, dtype=x.dtype, device=x.device)
+    out = torch.empty(B, dtype=rdt, device=x.device)
     ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() + i * n * x.element_size() for i in range(B)])
     with torch.cuda.device(x.device):
         ws, stream = workspace(x.device, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
-        st = L.mq_percentile_batch(ptrs, B, _DT[x.dtype], n, float(pct), out.data_ptr(), None, ws.data_ptr(),
+        st = L.mq_percentile_batch(ptrs, B, code, n, float(pct), out.data_ptr(), None, ws.data_ptr(),
                                    ws.numel(), stream.cuda_stream)
     _lib.check(st)
     # np.percentile returns NaN for a row that holds one (the select would rank it as the largest value)
@@ -112,16 +127,18 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0) -> torch.Tensor:
 
 
 @torch.no_grad()
-def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: bool = True) -> torch.Tensor:
+def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: bool = True,
+                     wide: bool = False) -> torch.Tensor:
     """np.percentile(x, pct) for each of a list of non-negative float32 / float64 device tensors of one dtype
     (any lengths; each flattened; unaligned views are copied): one set of launches per 64 arrays.  nan_check:
     as for percentile() (one small reduction per array; callers that already know which arrays hold a NaN --
-    e.g. from their means -- pass False and patch the results themselves)."""
+    e.g. from their means -- pass False and patch the results themselves).  wide: as for percentile()."""
     if not xs:
         raise ValueError("percentile_multi() needs at least one array")
     dtype, dev = xs[0].dtype, xs[0].device
     if dtype not in (torch.float32, torch.float64):
         raise ValueError("percentile_multi() takes float32 or float64 tensors")
+    code, rdt = _sel_dtype(dtype, wide)
     flat = []
     for x in xs:
         if x.dtype != dtype or x.device != dev or not x.is_cuda:
@@ -135,12 +152,12 @@ def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: b
     B = len(flat)
     has_nan = torch.stack([torch.isnan(x).any() for x in flat]) if nan_check else None
     L = _bind()
-    out = torch.empty(B, dtype=dtype, device=dev)
+    out = torch.empty(B, dtype=rdt, device=dev)
     ptrs = (ctypes.c_void_p * B)(*[x.data_ptr() for x in flat])
     ns = (ctypes.c_int64 * B)(*[x.numel() for x in flat])
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
-        st = L.mq_percentile_multi(ptrs, ns, B, _DT[dtype], float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
+        st = L.mq_percentile_multi(ptrs, ns, B, code, float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                    stream.cuda_stream)
     _lib.check(st)
     if has_nan is not None:

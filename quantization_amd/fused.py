@@ -69,7 +69,8 @@ class QuantResult:
     scale: Optional[torch.Tensor] = None    # float16 [nseg]
     zero_point: Optional[torch.Tensor] = None
     abs_err: Optional[torch.Tensor] = None  # float32 or float16 [rows, cols]
-    seg_sse: Optional[torch.Tensor] = None  # float64 [nseg]
+    seg_sse: Optional[torch.Tensor] = None  # float64 [nseg]: sums of squared errors per segment
+    seg_mse: Optional[torch.Tensor] = None  # float32 [nseg]: float32(sum / segment length), instead of seg_sse
     totals: Optional[torch.Tensor] = None   # float64 [2]: sum err^2, sum |err|
     abs_p99: Optional[torch.Tensor] = None  # float32 [B]: percentile of the float32 |error| (quantize_batch(p99=))
 
@@ -112,12 +113,17 @@ def _ptr(t):
 
 @torch.no_grad()
 def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
-             f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, totals=False,
-             out: Optional[QuantResult] = None) -> QuantResult:
+             f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, seg_mse=False,
+             totals=False, out: Optional[QuantResult] = None) -> QuantResult:
     """w: ROCm tensor viewed as [rows, cols] = [prod(shape[:-1]), shape[-1]], float16 / bfloat16 / float32.
 
-    abs_err: None, torch.float32 or torch.float16.  `out` may carry preallocated tensors to reuse.
+    abs_err: None, torch.float32 or torch.float16.  seg_sse: float64 sums of squared errors per segment; seg_mse:
+    the float32 mean squared error per segment instead (the per-vector MSE list of
+    quant_error_single_weight.py:56-71, whose entries are float32 means) -- one of the two.  `out` may carry
+    preallocated tensors to reuse.
     """
+    if seg_sse and seg_mse:
+        raise ValueError("seg_sse and seg_mse share one output slot: ask for one of them")
     if w.dtype not in _DTYPES:
         raise ValueError(f"unsupported weight dtype {w.dtype}")
     if not w.is_cuda:
@@ -149,6 +155,7 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
     res.zero_point = buf(res.zero_point, scale and fmt == _lib.INT_ASYM, (nseg,), torch.float16)
     res.abs_err = buf(res.abs_err, abs_err is not None, (rows, cols), abs_err or torch.float32)
     res.seg_sse = buf(res.seg_sse, seg_sse, (nseg,), torch.float64)
+    res.seg_mse = buf(res.seg_mse, seg_mse, (nseg,), torch.float32)
     res.totals = buf(res.totals, totals, (2,), torch.float64)
     if n == 0:
         if res.totals is not None:
@@ -159,7 +166,8 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
     o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale),
                       zero_point=_ptr(res.zero_point), abs_err=_ptr(res.abs_err),
                       abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
-                      seg_sse=_ptr(res.seg_sse), totals=_ptr(res.totals))
+                      seg_mse_f32=int(bool(seg_mse)), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
+                      totals=_ptr(res.totals))
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L_.mq_quantize_workspace_bytes(rows, cols, ctypes.byref(cfg)))
         st = L_.mq_quantize(w2.data_ptr(), _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ctypes.byref(o),
@@ -174,8 +182,8 @@ class _QuantItem(ctypes.Structure):
 
 @torch.no_grad()
 def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
-                   f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, totals=False,
-                   p99: Optional[float] = None, out: Optional[QuantResult] = None) -> QuantResult:
+                   f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, seg_mse=False,
+                   totals=False, p99: Optional[float] = None, out: Optional[QuantResult] = None) -> QuantResult:
     """quantize() for a stack of same-shaped weights w[B, rows, cols] (e.g. one projection of every layer):
     one fused launch per 32 tensors.  Every field of the result has a leading batch dimension.
 
@@ -183,6 +191,8 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     are produced (result.abs_p99, float32 [B]); needs abs_err=torch.float32."""
     if p99 is not None and abs_err != torch.float32:
         raise ValueError("p99 needs the float32 abs_err output")
+    if seg_sse and seg_mse:
+        raise ValueError("seg_sse and seg_mse share one output slot: ask for one of them")
     if isinstance(w, torch.Tensor):
         if w.dim() != 3:
             raise ValueError("quantize_batch() expects [B, rows, cols] or a list of [rows, cols] tensors")
@@ -236,6 +246,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     b_zp = buf("zero_point", scale and fmt == _lib.INT_ASYM, (B, nseg_pad), torch.float16)
     b_abs = buf("abs_err", abs_err is not None, (B, rows, cols), abs_err or torch.float32)
     b_sse = buf("seg_sse", seg_sse, (B, nseg_pad), torch.float64)
+    b_mse = buf("seg_mse", seg_mse, (B, nseg_pad), torch.float32)
     b_tot = buf("totals", totals, (B, 2), torch.float64)
     res.abs_p99 = buf("abs_p99", p99 is not None, (B,), torch.float32)
     res._bufs = bufs
@@ -243,6 +254,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     res.scale = None if b_scale is None else b_scale[:, :nseg]
     res.zero_point = None if b_zp is None else b_zp[:, :nseg]
     res.seg_sse = None if b_sse is None else b_sse[:, :nseg]
+    res.seg_mse = None if b_mse is None else b_mse[:, :nseg]
     if n == 0 or B == 0:
         if res.totals is not None:
             res.totals.zero_()
@@ -257,7 +269,8 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
         items[i].w = tensors[i].data_ptr()
         items[i].out = _lib.QuantOut(deq=at(b_deq, i), codes=at(b_codes, i), scale=at(b_scale, i),
                                      zero_point=at(b_zp, i), abs_err=at(b_abs, i), abs_err_dtype=aed,
-                                     seg_sse=at(b_sse, i), totals=at(b_tot, i))
+                                     seg_mse_f32=int(bool(seg_mse)), seg_sse=at(b_mse if seg_mse else b_sse, i),
+                                     totals=at(b_tot, i))
     L_ = _lib.lib()
     if not getattr(L_, "_batch_bound", False):
         L_.mq_quantize_batch_workspace_bytes.restype = ctypes.c_size_t
@@ -290,10 +303,12 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
 @torch.no_grad()
 def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_dtype=torch.float16,
                    neg_inf_zero=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False,
-                   totals=False) -> QuantResult:
+                   seg_mse=False, totals=False) -> QuantResult:
     """quantize() for a value table given as an explicit ascending list (mq_quantize_table): math is
     _lib.TABLE_F16 (float16 op by op; codes / scale float16), _lib.TABLE_F32 (float32; codes / scale float32,
     deq float16 or float32) or _lib.TABLE_MX (shared power-of-two exponent per group; deq only)."""
+    if seg_sse and seg_mse:
+        raise ValueError("seg_sse and seg_mse share one output slot: ask for one of them")
     if w.dtype not in _DTYPES:
         raise ValueError(f"unsupported weight dtype {w.dtype}")
     if not w.is_cuda:
@@ -330,6 +345,7 @@ def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_d
     res.scale = buf(scale, (nseg,), wide)
     res.abs_err = buf(abs_err is not None, (rows, cols), abs_err or torch.float32)
     res.seg_sse = buf(seg_sse, (nseg,), torch.float64)
+    res.seg_mse = buf(seg_mse, (nseg,), torch.float32)
     res.totals = buf(totals, (2,), torch.float64)
     if n == 0:
         if res.totals is not None:
@@ -338,7 +354,8 @@ def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_d
     L_ = _lib.lib()
     o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale), zero_point=None,
                       abs_err=_ptr(res.abs_err), abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
-                      seg_sse=_ptr(res.seg_sse), totals=_ptr(res.totals))
+                      seg_mse_f32=int(bool(seg_mse)), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
+                      totals=_ptr(res.totals))
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L_.mq_quantize_table_workspace_bytes(rows, cols, ctypes.byref(cfg)))
         st = L_.mq_quantize_table(w2.data_ptr(), _DTYPES[w.dtype], rows, cols, ctypes.byref(cfg), ctypes.byref(o),

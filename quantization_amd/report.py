@@ -60,25 +60,27 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
     K, C = w.shape
     L = C if granularity(group_size) == "per-channel" else group_size
     scratch = scratch if scratch is not None else {}
+    single = form == "single"
     if table in TABLE_LISTS:
-        res = quantize_table(w, TABLE_LISTS[table], _lib.TABLE_F16, group_size, deq=(form == "multi"), codes=False,
-                             scale=False, abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"),
-                             totals=True)
+        res = quantize_table(w, TABLE_LISTS[table], _lib.TABLE_F16, group_size, deq=not single, codes=False,
+                             scale=False, abs_err=torch.float32 if abs_p99 else None, seg_mse=single, totals=True)
     else:
-        res = quantize(w, fmt, bits, group_size, table, deq=(form == "multi"), codes=False, scale=False,
-                       abs_err=torch.float32 if abs_p99 else None, seg_sse=(form == "single"), totals=True,
+        res = quantize(w, fmt, bits, group_size, table, deq=not single, codes=False, scale=False,
+                       abs_err=torch.float32 if abs_p99 else None, seg_mse=single, totals=True,
                        out=scratch.get("res"))
         scratch["res"] = res
     rec = torch.zeros(len(RECORD_FIELDS), dtype=torch.float64, device=w.device)
     rec[0] = w.numel()
     rec[1:3] = res.totals
-    if form == "single":
-        per_vec = true_div(res.seg_sse, L)
+    if single:
+        # float32 list entries, float64 percentile arithmetic; the list's mean is the tensor MSE (see model_records)
+        rec[3] = res.totals[0] / w.numel()
+        rec[4] = percentile(res.seg_mse, 99, wide=True)
     else:
         col = error_stats(w.half() if w.dtype != torch.float16 else w, res.deq, cols=True, totals=False)["col_sse"]
         per_vec = true_div(col, K) if L == C else true_div(col.reshape(C // L, L).sum(dim=1), K * L)
-    rec[3] = per_vec.mean()
-    rec[4] = percentile(per_vec, 99)
+        rec[3] = per_vec.mean()
+        rec[4] = percentile(per_vec, 99)
     if abs_p99:
         rec[5] = percentile(res.abs_err, 99).double()
     return rec
@@ -94,8 +96,16 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     of quant_weight.py:660-704 fused in: layers are grouped by (shape, dtype) -- a transformer has a handful --
     and every group goes through ONE fused launch per 32 tensors (their pointers, no stacking copy); with
     abs_p99 the P99 of |err| is selected inside that launch.  max_err_bytes bounds the float32 |err| scratch
-    of one launch.  return_vecs: also return the per-vector MSE lists (float64, one per weight, in the order of
-    `weights`) -- what a model-wide percentile over several GPUs is taken from (distributed.joint_percentile)."""
+    of one launch.  return_vecs: also return the per-vector MSE lists (float32, one per weight, in the order of
+    `weights`) -- what a model-wide percentile over several GPUs is taken from (distributed.joint_percentile with
+    wide=True).
+
+    The per-vector list holds float32 values, as the scripts' does (compute_mse returns float(np.float32 mean),
+    quant_error_single_weight.py:46-48): the kernels write float32(sum / L) per segment, the P99 is selected on the
+    float32 bits and interpolated in float64 like np.percentile of the float64 array of those values (:79).
+    mse_rep (:78, the mean of the list) is the tensor's squared-error sum over its element count: every vector of
+    a weight has the same length, so the two are the same number up to the float32 rounding of the list entries
+    (6e-8 relative), and no pass over the list is needed for it."""
     fmt, table = format_code(datatype)
     weights = list(weights)
     if not weights:
@@ -105,42 +115,43 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         if return_vecs:
             raise ValueError("return_vecs is not available for the explicit-list tables")
         return torch.stack([layer_record(w, datatype, bits, group_size, abs_p99=abs_p99) for w in weights])
-    out = torch.zeros(len(weights), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
     groups: Dict[Tuple, List[int]] = {}
     for i, w in enumerate(weights):
         if w.dim() != 2:
             raise ValueError("model_records() takes 2-D weights")
         groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
-    vec_rows, vecs = [], []  # per-vector MSE lists of ALL layers: one set of select launches at the end
+    # per-vector MSE lists of ALL layers: one set of select launches at the end; the launches' small results are
+    # gathered with one concatenation and one permutation (no per-launch host <-> device traffic)
+    vec_rows, vecs, keep, tots, p99s = [], [], [], [], []
     for (shape, _), idx in groups.items():
         K, C = shape
-        L = C if granularity(group_size) == "per-channel" else group_size
         per = K * C * 4 if abs_p99 else 1
         chunk = max(1, min(32, max_err_bytes // per))
-        res = None
         for lo in range(0, len(idx), chunk):
             sel = idx[lo:lo + chunk]
-            if res is not None and len(sel) != chunk:
-                res = None  # the last, shorter chunk gets buffers of its own size
+            # (every chunk keeps its own result: the lists are read by the selection after the last launch)
             res = quantize_batch([weights[i] for i in sel], fmt, bits, group_size, table, deq=False, codes=False,
-                                 scale=False, abs_err=torch.float32 if abs_p99 else None, seg_sse=True, totals=True,
-                                 p99=pct if abs_p99 else None, out=res)
-            rows = torch.as_tensor(sel, device=dev)
-            rec = torch.zeros(len(sel), len(RECORD_FIELDS), dtype=torch.float64, device=dev)
-            rec[:, 0] = K * C
-            rec[:, 1:3] = res.totals
-            per_vec = true_div(res.seg_sse, L)        # a fresh tensor: the chunk's buffers are reused
-            rec[:, 3] = per_vec.mean(dim=1)
+                                 scale=False, abs_err=torch.float32 if abs_p99 else None, seg_mse=True, totals=True,
+                                 p99=pct if abs_p99 else None)
+            tots.append(res.totals)
             if abs_p99:
-                rec[:, 5] = res.abs_p99.double()
-            out[rows] = rec
+                p99s.append(res.abs_p99)
+                res.abs_err = None
+                res._bufs.pop("abs_err", None)   # the |err| scratch of this launch is free for the next one
+            keep.append(res)
             vec_rows += sel
-            vecs += [per_vec[i] for i in range(len(sel))]
-    for lo in range(0, len(vecs), 4096):
-        out[torch.as_tensor(vec_rows[lo:lo + 4096], device=dev), 4] = percentile_multi(vecs[lo:lo + 4096], pct,
-                                                                                        nan_check=False)
+            vecs += list(res.seg_mse.unbind(0))
+    p99v = torch.cat([percentile_multi(vecs[lo:lo + 4096], pct, nan_check=False, wide=True)
+                      for lo in range(0, len(vecs), 4096)])
+    host = torch.tensor([[float(weights[i].numel()), float(i)] for i in vec_rows], dtype=torch.float64).to(dev)
+    numel, tot = host[:, 0], torch.cat(tots)
+    mse = tot[:, 0] / numel
     # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
-    out[:, 4] = torch.where(torch.isnan(out[:, 3]), out[:, 3], out[:, 4])
+    p99v = torch.where(torch.isnan(mse), mse, p99v)
+    a99 = torch.cat(p99s).double() if abs_p99 else torch.zeros_like(mse)
+    rec = torch.stack([numel, tot[:, 0], tot[:, 1], mse, p99v, a99], dim=1)
+    out = torch.empty_like(rec)
+    out[host[:, 1].long()] = rec            # launch order -> the order of `weights`
     if return_vecs:
         order = {i: k for k, i in enumerate(vec_rows)}
         return out, [vecs[order[i]] for i in range(len(weights))]

@@ -52,6 +52,60 @@ def test_joint_percentile_single_process():
         assert got.tobytes() == np.asarray(want, dtype).tobytes()
 
 
+def test_wide_percentiles_match_numpy_on_the_float64_array():
+    """wide=True: float32 values standing for the float64 array that holds them -- vec = np.array(per_vec) of
+    float(np.float32) means, quant_error_single_weight.py:74-79.  Bit for bit np.percentile of that float64 array, on
+    every route: one-launch short arrays, the two-pass route, sample + bracket (2^21 values and more), batches,
+    lists of different lengths, the joint selection over several tensors."""
+    from quantization_amd import error_metrics as em
+    from quantization_amd.distributed import joint_percentile
+    rng = np.random.default_rng(8)
+    arrays = [np.abs(rng.standard_normal(n)).astype(np.float32) ** 2 * s
+              for n, s in ((1, 1.0), (5, 10.0), (1000, 1e-6), (40000, 1e-7), (524288, 3e-8), (3000001, 1e-3))]
+    arrays[3][:100] = arrays[3][200]          # ties
+    for pct in (99, 50, 0, 100, 99.9):
+        want = [np.percentile(a.astype(np.float64), pct) for a in arrays]
+        dev = [torch.from_numpy(a).cuda() for a in arrays]
+        for a, x in zip(want, dev):
+            got = em.percentile(x, pct, wide=True)
+            assert got.dtype == torch.float64 and got.cpu().numpy().tobytes() == np.float64(a).tobytes(), (pct, x.numel())
+        got = em.percentile_multi(dev, pct, wide=True).cpu().numpy()
+        assert got.tobytes() == np.asarray(want, np.float64).tobytes(), pct
+        j = joint_percentile(dev, pct, wide=True)
+        assert j.dtype == torch.float64
+        assert j.cpu().numpy().tobytes() == np.float64(np.percentile(np.concatenate(arrays).astype(np.float64), pct)).tobytes()
+    m = np.abs(rng.standard_normal((7, 4096))).astype(np.float32)
+    got = em.percentile_batch(torch.from_numpy(m).cuda(), 99, wide=True).cpu().numpy()
+    assert got.tobytes() == np.percentile(m.astype(np.float64), 99, axis=1).tobytes()
+    with pytest.raises(ValueError):
+        em.percentile(torch.zeros(8, dtype=torch.float64).cuda(), 99, wide=True)
+
+
+def test_model_records_vs_oracle(oracle):
+    """The model sweep's records against the scripts' numpy arithmetic on the oracle's dequantized weights: the
+    per-vector list holds float32 means as the scripts' does, so mse_p99 / mse_rep agree to the float32 summation
+    order (1e-6)."""
+    from quantization_amd import report
+    rng = np.random.default_rng(21)
+    shapes = [(64, 512), (32, 1024), (64, 512)]
+    w16 = [(rng.standard_normal(s) * 0.02).astype(np.float16) for s in shapes]
+    ws = [torch.from_numpy(w).cuda() for w in w16]
+    for datatype in ("int8", "int8_asym", "fp8_e4m3"):
+        for gs in (None, 32, 128):
+            rec, vecs = report.model_records(ws, datatype, 8, gs, return_vecs=True)
+            rec = rec.cpu().numpy()
+            for i, w in enumerate(w16):
+                ce, el = _np_record(oracle, w, datatype, gs, "single")
+                assert abs(rec[i, 1] / rec[i, 0] - ce["mse_tensor"]) <= 1e-6 * ce["mse_tensor"]
+                assert abs(rec[i, 3] - ce["mse_rep"]) <= 1e-6 * ce["mse_rep"]
+                assert abs(rec[i, 4] - ce["mse_p99"]) <= 1e-6 * ce["mse_p99"]
+                assert np.float32(rec[i, 5]).tobytes() == np.float32(el["p99"]).tobytes()
+                v = vecs[i].cpu().numpy()
+                assert v.dtype == np.float32 and v.size == w.size // (gs or w.shape[1])
+                # the selection itself is exact: np.percentile of the list the kernel wrote
+                assert rec[i, 4] == np.percentile(v.astype(np.float64), 99)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)

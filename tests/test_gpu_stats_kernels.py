@@ -133,3 +133,40 @@ def test_float16_error_is_exact_on_every_pattern():
             else:
                 keep = torch.ones_like(wt, dtype=torch.bool)
             assert torch.equal(a.abs_err[keep], b.abs_err[keep].float()), (code, table, bits, gs)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_segment_mse_float32_form(dt):
+    """seg_mse (mq_quant_out.seg_mse_f32 = 1): every kernel scope writes float32(sum * (1 / L)) of the float64 sum
+    it writes as seg_sse -- statistics-only kernels, the kernels with element outputs, the per-element kernel
+    (ragged L), per-tensor scope and the explicit-list table kernels."""
+    from quantization_amd import _lib, fused
+    from quantization_amd.fused import quantize, quantize_batch, quantize_table
+
+    def check(a, b, L, what):
+        want = (b.double() * (1.0 / L)).float()
+        assert a.dtype == torch.float32 and a.shape == b.shape, what
+        assert torch.equal(a.view(torch.int32), want.view(torch.int32)), what
+
+    for k, (rows, cols, gs) in enumerate(SHAPES + [(5, 1001, None), (4, 512, -1)]):
+        w = _inputs(rows, cols, 300 + k)
+        wt = (w.half() if dt == "f16" else w.bfloat16()).cuda()
+        L = rows * cols if gs == -1 else (cols if gs is None else gs)
+        for code, table, bits in ((_lib.INT_SYM, None, 8), (_lib.INT_ASYM, None, 8), (_lib.LUT_FP, "fp8_e4m3", 8),
+                                  (_lib.LUT_FP, "fp4", 4)):
+            for outs in (dict(deq=False, codes=False, scale=False), dict(deq=True, codes=True, scale=True)):
+                a = quantize(wt, code, bits, gs, table, seg_mse=True, totals=True, **outs)
+                b = quantize(wt, code, bits, gs, table, seg_sse=True, totals=True, **outs)
+                check(a.seg_mse, b.seg_sse, L, (rows, cols, gs, code, table, tuple(outs.values())))
+                assert torch.equal(a.totals.view(torch.int64), b.totals.view(torch.int64))
+    w = (torch.randn(3, 24, 256, generator=torch.Generator().manual_seed(5)) * 0.02).to(
+        torch.float16 if dt == "f16" else torch.bfloat16).cuda()
+    a = quantize_batch(w, _lib.INT_SYM, 8, 64, deq=False, codes=False, scale=False, seg_mse=True)
+    b = quantize_batch(w, _lib.INT_SYM, 8, 64, deq=False, codes=False, scale=False, seg_sse=True)
+    check(a.seg_mse, b.seg_sse, 64, "batch")
+    for gs in (64, None, -1):
+        a = quantize_table(w[0], fused.TABLE_LISTS["flint4"], _lib.TABLE_F16, gs, seg_mse=True)
+        b = quantize_table(w[0], fused.TABLE_LISTS["flint4"], _lib.TABLE_F16, gs, seg_sse=True)
+        check(a.seg_mse, b.seg_sse, 24 * 256 if gs == -1 else (gs or 256), f"table {gs}")
+    with pytest.raises(ValueError):
+        quantize(w[0], _lib.INT_SYM, 8, 64, seg_sse=True, seg_mse=True)
