@@ -140,6 +140,9 @@ struct SegP {
   float sf;    // (float)s
   float r;     // ~1 / sf (v_rcp_f32, at most 1 ulp off: enough for div_h, see there)
   bool slow;   // this segment must take the per-element path
+  // statistics-only integer formats (div_pk16): P = 2^k with s * P in [1, 2), s * P and RN16(1 / (s * P)), each
+  // as a pair of equal float16 halves
+  uint32_t pk_p, pk_s, pk_r;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -555,6 +558,29 @@ __device__ __forceinline__ h16x2 div_pk(uint32_t vw, const SegP& sp) {
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_fmaf(ra, sp.r, q0a)), "v"(__builtin_fmaf(rb, sp.r, q0b)));
   return as_h2(x);
 }
+// h(v / s) for both halves of vw in packed float16 arithmetic, four instructions per pair:
+//   v' = v P,  q0 = v' r,  rem = fma(-q0, s', v'),  q1 = fma(rem, r, q0)      s' = s P in [1, 2), r = RN16(1 / s')
+// P is a power of two, so v' / s' = v / s; it lifts the remainder out of the float16 subnormal range, where the
+// fma could not hold it.  For EVERY finite float16 v and every float16 s in [2^-15, 0x70E2] with |v / s| <= 600:
+// q1 has the bits of the correctly rounded quotient whenever |v / s| >= 2^-4, and rint(q1) = rint(h(v / s))
+// always (below 2^-4 the remainder may be inexact and q1 a few ulp off: both round to 0) -- enumerated on the
+// CPU by tests/tools/div16_exhaustive.c and on the device by mq_selfcheck_div16.  That is all the integer formats
+// need from the quotient.  The sign of a zero quotient follows v.
+__device__ __forceinline__ void pk_div_params(SegP& sp) {
+  const int k = 1 - __builtin_amdgcn_frexp_expf(sp.sf);  // sf = m 2^e, m in [0.5, 1): s 2^k in [1, 2)
+  const float s1 = __builtin_ldexpf(sp.sf, k);
+  sp.pk_p = dup16(h_bits((half_t)__builtin_ldexpf(1.0f, k)));  // (k <= 15 is the caller's test: s >= 2^-15)
+  sp.pk_s = dup16(h_bits((half_t)s1));
+  // v_rcp_f32 is within 1 ulp of 1 / s'; for each of the 1024 values of s' every float32 within 2 ulp of 1 / s'
+  // rounds to the same float16 (same test program)
+  sp.pk_r = dup16(h_bits((half_t)__builtin_amdgcn_rcpf(s1)));
+}
+__device__ __forceinline__ h16x2 div_pk16(uint32_t vw, const SegP& sp) {
+  const h16x2 v1 = as_h2(vw) * as_h2(sp.pk_p);
+  const h16x2 q0 = v1 * as_h2(sp.pk_r);
+  const h16x2 rem = __builtin_elementwise_fma(-q0, as_h2(sp.pk_s), v1);
+  return __builtin_elementwise_fma(rem, as_h2(sp.pk_r), q0);
+}
 // |nearest table value| for the two float16 quotients in xw, for a table WITHOUT subnormals; vw: the weights (the
 // quotient has their sign, and a zero quotient rounds to zero whatever its sign).  lut_round_pk without the sign
 // handling and without the upper clamp: the caller knows |x| <= (1 + 2^-9) * largest entry, which rounds to the
@@ -571,7 +597,8 @@ __device__ __forceinline__ uint32_t lut_round_mag_pk(uint32_t xw, uint32_t vw, c
 }
 // One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements are ADDED to the caller's
 // (the caller carries everything above a few vectors in float64).
-template <int FMT>
+// PK16: the integer formats divide in packed float16 (div_pk16; sp must carry pk_p / pk_s / pk_r: stats_params).
+template <int FMT, bool PK16 = false>
 __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 raw, const SegP& sp, float& sse,
                                              float& sabs) {
   const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
@@ -580,7 +607,7 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t vw = raw[k];
-    const h16x2 x = div_pk(vw, sp);
+    const h16x2 x = (PK16 && !MQ_IS_LUT(FMT)) ? div_pk16(vw, sp) : div_pk(vw, sp);
     h16x2 e;
     if constexpr (FMT == MQ_INT_SYM) {
       e = as_h2(vw) - ((x + magic) - magic) * s2;
@@ -1133,6 +1160,20 @@ __device__ __forceinline__ u32x4 stats_load(const char* ptr) {
   if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ptr));
   else return *reinterpret_cast<const u32x4*>(ptr);
 }
+// The statistics kernels read the weights through a raw buffer descriptor (base, size in bytes): a load whose
+// offset lies past the size returns zeros and touches no memory.  A lane past the end of a ragged row or of the
+// last partial step, and a whole prefetch past the wave's last step, are such loads -- the load instructions
+// stay unconditional.  (A branch around a load makes the compiler wait for EVERY outstanding memory operation
+// where the paths merge, s_waitcnt vmcnt(0), the prefetch just issued included; with straight-line loads it
+// counts: vmcnt(7), (6), ... as the vectors of the older buffer are consumed.)
+#define MQ_STATS_OOB 0xffff0000u   // an offset past every admitted tensor (the host keeps them below 0xf0000000)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stats_rsrc(const QuantParams& p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, (int)(uint32_t)(p.n * 2), 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 stats_bload(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, NT ? 2 : 0));
+}
 // One lane's reduction word over NV vectors: absmax bits, or (min | max << 16).  v_pk_maximum3 / minimum3_f16 take
 // two new words per instruction and, unlike v_pk_max / min_f16, return a NaN when an operand is one (a NaN in the
 // segment must reach the parameters: torch.amax / amin propagate it).
@@ -1165,8 +1206,14 @@ __device__ __forceinline__ uint32_t stats_op(uint32_t a, uint32_t b) {
 template <int FMT>
 __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p) {
   if (!p.qmax_recip_ok) {
-    if constexpr (FMT == MQ_INT_ASYM) return params_minmax(red, p);
-    else return params_absmax(red, p);
+    SegP sp;
+    if constexpr (FMT == MQ_INT_ASYM) sp = params_minmax(red, p);
+    else sp = params_absmax(red, p);
+    if constexpr (!MQ_IS_LUT(FMT)) {
+      sp.slow = sp.slow || sp.sf < 0x1p-15f;
+      pk_div_params(sp);
+    }
+    return sp;
   }
   const half_t lo = h_from_bits(0x00A8u), hi = h_from_bits(0x70E2u);
   SegP sp;
@@ -1185,17 +1232,19 @@ __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p)
     // error of quant8_stats -- a row that does not lie on one side of zero (then the clamp to [0, qmax] removes
     // at most one step from a code, see tests/tools/sterbenz_exhaustive.c)
     sp.slow = !(big * sp.r < 500.0f) || !((float)h_from_bits(range) < 65504.0f) || s0 > hi || !(s0 == s0) ||
-              (float)rmin > 0.f || (float)rmax < 0.f;
-    if (sp.slow) sp = params_minmax(red, p);
-    sp.slow = sp.slow || s0 > hi || (float)rmin > 0.f || (float)rmax < 0.f;
+              (float)rmin > 0.f || (float)rmax < 0.f || sp.sf < 0x1p-15f;
+    if (sp.slow) { sp = params_minmax(red, p); sp.slow = true; }
+    else pk_div_params(sp);
   } else {
     const float q0 = mix_mul_lo(red, p.rqmax);
     const half_t s0 = (half_t)__builtin_fmaf(mix_rem_lo(q0, p.qmax, red), p.rqmax, q0);
     finish_params(sp, __builtin_fminf16(__builtin_fmaxf16(s0, lo), hi));
     sp.zp = (half_t)0;
-    // inf / NaN in the segment, or a scale cut by the upper clamp (then |v / s| may pass qmax)
-    sp.slow = red >= 0x7c00u || s0 > hi;
+    // inf / NaN in the segment, a scale cut by the upper clamp (then |v / s| may pass qmax), or one below the
+    // range of the packed division
+    sp.slow = red >= 0x7c00u || s0 > hi || sp.sf < 0x1p-15f;
     if (sp.slow) { sp = params_absmax(red, p); sp.slow = true; }
+    else if constexpr (!MQ_IS_LUT(FMT)) pk_div_params(sp);
   }
   return sp;
 }
@@ -1209,7 +1258,7 @@ __device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4*
   float q = 0.f, ab = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    quant8_stats<FMT>(p, raw[j], sp, q, ab);
+    quant8_stats<FMT, true>(p, raw[j], sp, q, ab);
     if ((j & 1) == 1 || j == NV - 1) { sse += (double)q; q = 0.f; }
     if ((j & 3) == 3 || j == NV - 1) { sabs += (double)ab; ab = 0.f; }
     // one vector's arithmetic at a time: interleaving all NV of them costs 100+ registers of temporaries
@@ -1247,16 +1296,13 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   const uint32_t loff = (uint32_t)(team * (64 * T) + tl * 16);  // this lane's bytes inside the step's 4 KiB
   double acc_sse = 0.0, acc_abs = 0.0;
   bool seen_slow = false;
+  const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
+  // this lane's four vectors of step t; zeros for a lane past the last segment and for a step past the last one
   auto issue = [&](int64_t t, u32x4* dst) __attribute__((always_inline)) {
-    const char* sb = wb + t * 4096 + loff;
-    if (t < full) {
+    const bool in = t < full || t * SPW + team < p.nseg;
+    const uint32_t off = in ? (uint32_t)(t * 4096) + loff : MQ_STATS_OOB;
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = stats_load<false>(sb + j * (16 * T));
-    } else {  // the last, partial step
-      const bool in = t * SPW + team < p.nseg;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = in ? stats_load<false>(sb + j * (16 * T)) : u32x4{0, 0, 0, 0};
-    }
+    for (int j = 0; j < NV; ++j) dst[j] = stats_bload<false>(rs, off + j * (16 * T));
   };
   auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take) __attribute__((always_inline)) {
     const int64_t seg = t * SPW + team;
@@ -1284,17 +1330,17 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     finish(t, sp, s, ab, !sp.slow);
   };
   // two register buffers take turns, so that the next step's loads are in flight while this one is computed and
-  // no vector is copied between registers
+  // no vector is copied between registers (past the wave's last step the prefetch loads nothing, see stats_bload)
   {
     u32x4 bufa[NV], bufb[NV];
     int64_t t = gw;
-    if (t < steps) issue(t, bufa);
+    issue(t, bufa);
     while (t < steps) {
       const int64_t t1 = t + nwaves, t2 = t1 + nwaves;
-      if (t1 < steps) issue(t1, bufb);
+      issue(t1, bufb);
       step(t, bufa);
       if (t1 >= steps) break;
-      if (t2 < steps) issue(t2, bufa);
+      issue(t2, bufa);
       step(t1, bufb);
       t = t2;
     }
@@ -1323,7 +1369,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
 // (The second launch bound -- waves per SIMD -- and the scheduling barriers of stats_vectors keep the compiler from
 //  interleaving all NV vectors' arithmetic, which took 160 .. 220 registers.)
 template <int FMT, bool BF16, int NV, int WPR>
-__global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const QuantBatch b) {
+__global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k_stats_row(const QuantBatch b) {
   const QuantParams p = batch_params(b);
   __shared__ double lds[32];
   __shared__ uint32_t xr[2][4];
@@ -1340,15 +1386,17 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const Quan
   double acc_sse = 0.0, acc_abs = 0.0;
   int parity = 0;
   bool seen_slow = false;
+  const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
+  // this lane's NV vectors of a row; zeros for vectors past the row's end and for a row past the last one
   auto issue = [&](int64_t row, u32x4* dst) __attribute__((always_inline)) {
-    const char* sb = wb + row * row_bytes + loff;
+    const uint32_t base = row < p.nseg ? (uint32_t)(row * row_bytes) + loff : MQ_STATS_OOB;
     if (whole) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) dst[j] = stats_load<true>(sb + j * (1024 * WPR));
+      for (int j = 0; j < NV; ++j) dst[j] = stats_bload<true>(rs, base + j * (1024 * WPR));
     } else {
 #pragma unroll
       for (int j = 0; j < NV; ++j)
-        dst[j] = (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? stats_load<true>(sb + j * (1024 * WPR)) : u32x4{0, 0, 0, 0};
+        dst[j] = stats_bload<true>(rs, (j * WPR + sub) * 64 + lane < p.vecs_per_seg ? base + j * (1024 * WPR) : MQ_STATS_OOB);
     }
   };
   // this row's parameters from the lane's vectors (every wave of the row gets the same)
@@ -1411,16 +1459,17 @@ __global__ __launch_bounds__(256, (NV <= 4 ? 6 : 4)) void k_stats_row(const Quan
     parity ^= 1;
   };
   if constexpr (NV <= 8) {
-    // two register buffers take turns: the next row's loads are in flight while this one is computed
+    // two register buffers take turns: the next row's loads are in flight while this one is computed (past the
+    // last row the prefetch loads nothing, see stats_bload)
     u32x4 bufa[NV], bufb[NV];
     int64_t row = first;
-    if (row < p.nseg) issue(row, bufa);
+    issue(row, bufa);
     while (row < p.nseg) {
       const int64_t r1 = row + stride, r2 = r1 + stride;
-      if (r1 < p.nseg) issue(r1, bufb);
+      issue(r1, bufb);
       step(row, bufa);
       if (r1 >= p.nseg) break;
-      if (r2 < p.nseg) issue(r2, bufa);
+      issue(r2, bufa);
       step(r1, bufb);
       row = r2;
     }
@@ -2103,8 +2152,9 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   // statistics only: the kernels compiled without the output stores
   const int kmode = (sel_mode == SEL_FEED_OFF && p.need_err && !p.deq && !p.codes && !p.abs_err) ? SEL_STATS_ONLY : sel_mode;
   // (tables without subnormals and more than 6 mantissa bits need the upper clamp lut_round_mag_pk leaves out)
+  // (... and a tensor inside the 32-bit offsets of the buffer loads)
   const bool stats_kernels = kmode == SEL_STATS_ONLY && vec_ok && (w_dtype == MQ_F16 || w_dtype == MQ_BF16) &&
-                             !(fmt == MQ_LUT_FP && cfg->man_bits > 6);
+                             !(fmt == MQ_LUT_FP && cfg->man_bits > 6) && n * 2 <= 0xf0000000ll;
   if (kmode == SEL_STATS_ONLY && scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0 && !sampled) {
     // groups of 32 * 2^k elements: the kernels that hold four vectors of one segment per lane
     team_log2 = ilog2_ceil(p.L / 32);
