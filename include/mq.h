@@ -101,6 +101,16 @@ int mq_profile_reserve(int64_t launches);
 int mq_profile_begin(void);
 int mq_profile_end(double* total_ms, int64_t* launches);
 
+/*
+ * Device self-check (no counterpart in the reference): the statistics-only kernels of the integer formats take the
+ * float16 quotient v / scale in packed float16 arithmetic (a scaled reciprocal multiply and two fused corrections).
+ * This enumerates every float16 scale in [2^-15, 0x70E2] against every finite float16 value with |v / scale| <= 600
+ * on the device and compares with the float32 division of the other kernels (= torch's w / scale,
+ * quant_weight.py:230-266).  counts (DEVICE, 3 x uint64, 8-byte aligned) receives: pairs checked, pairs whose
+ * rounded integer differs, pairs with |v / scale| >= 2^-4 whose float16 bits differ; the last two must be 0.
+ */
+int mq_selfcheck_div16(uint64_t* counts, void* hip_stream);
+
 /* Bytes of device workspace mq_quantize needs for this shape (reduction slots + per-block partials). */
 size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
 

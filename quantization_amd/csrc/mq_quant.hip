@@ -2011,6 +2011,48 @@ extern "C" size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t, int6
   return (size_t)(count < 1 ? 1 : (count > MQ_MAX_BATCH ? MQ_MAX_BATCH : count)) * ws_slice_bytes();
 }
 
+// ---- device self-check of the packed float16 division -------------------------------------------------------
+// One workgroup per float16 scale in [2^-15, 0x70E2]; every finite float16 v of either sign with |v / s| <= 600:
+// div_pk16 (with this device's v_rcp_f32 in pk_div_params) against the float32 division sequence of the general
+// kernels (div_f: equal to the IEEE quotient on this domain, tests/tools/div_exhaustive.c).
+// counts[0] pairs checked, [1] pairs whose rint differs, [2] pairs with |v / s| >= 2^-4 whose bits differ.
+__global__ __launch_bounds__(256) void k_selfcheck_div16(unsigned long long* counts) {
+  const uint32_t sb = 0x0200u + blockIdx.x;
+  SegP sp;
+  finish_params(sp, h_from_bits(sb));
+  sp.zp = (half_t)0;
+  sp.slow = false;
+  pk_div_params(sp);
+  unsigned long long n = 0, bad_rint = 0, bad_bits = 0;
+  for (uint32_t vb = threadIdx.x; vb < 0x7c00u; vb += blockDim.x) {
+    const half_t v = h_from_bits(vb);
+    const half_t want = (half_t)div_f((float)v, sp);
+    if (!((float)want <= 600.0f)) continue;
+    const h16x2 got = div_pk16(vb | ((vb | 0x8000u) << 16), sp);  // (+v, -v)
+    n += 2;
+    const float w = (float)want;
+    bad_rint += (__builtin_rintf((float)got[0]) != __builtin_rintf(w)) + (__builtin_rintf((float)got[1]) != __builtin_rintf(-w));
+    if (w >= 0.0625f) bad_bits += (h_bits(got[0]) != h_bits(want)) + (h_bits(got[1]) != (h_bits(want) | 0x8000u));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n += __shfl_xor(n, off); bad_rint += __shfl_xor(bad_rint, off); bad_bits += __shfl_xor(bad_bits, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], n); atomicAdd(&counts[1], bad_rint); atomicAdd(&counts[2], bad_bits);
+  }
+}
+extern "C" int mq_selfcheck_div16(uint64_t* counts_device, void* hip_stream) {
+  if (!counts_device) return MQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(counts_device) % 8) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  MQ_HIP(hipMemsetAsync(counts_device, 0, 3 * sizeof(uint64_t), st));
+  hipLaunchKernelGGL(k_selfcheck_div16, dim3(0x70E2u - 0x0200u + 1u), dim3(256), 0, st,
+                     reinterpret_cast<unsigned long long*>(counts_device));
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
 static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; }
 
 // One launch (plus one finalize launch when totals are requested) for up to MQ_MAX_BATCH tensors.

@@ -20,7 +20,7 @@ def t(gs, **outs):
         best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
     return best
 for gs in (128, 32, None):
-    full = t(gs, deq=False, codes=False, scale=True, seg_sse=True, totals=True)
-    nosc = t(gs, deq=False, codes=False, scale=False, seg_sse=True, totals=True)
-    noseg = t(gs, deq=False, codes=False, scale=False, seg_sse=False, totals=True)
+    full = t(gs, deq=False, codes=False, scale=True, seg_mse=True, totals=True)
+    nosc = t(gs, deq=False, codes=False, scale=False, seg_mse=True, totals=True)
+    noseg = t(gs, deq=False, codes=False, scale=False, seg_mse=False, totals=True)
     print(f"MQ_MAX_BLOCKS={os.environ.get('MQ_MAX_BLOCKS')} gs={gs}: scale+seg_sse+totals {full:6.1f} us | seg_sse+totals {nosc:6.1f} | totals only {noseg:6.1f}", flush=True)

@@ -37,6 +37,34 @@ __global__ __launch_bounds__(256) void k_read_store(const u32x4* __restrict__ w,
   }
 }
 
+
+// the 4 B x 64 lanes per 4 KiB results kept in registers and written at the end: a wave takes K CONSECUTIVE
+// 4 KiB steps, so that its K x 256 B of results are one contiguous run
+template <int K, bool NT>
+__global__ __launch_bounds__(256) void k_read_store_deferred(const u32x4* __restrict__ w, char* __restrict__ st, int64_t nvec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  const int64_t tiles = nvec / 256, chunks = tiles / K;
+  for (int64_t c = gw; c < chunks; c += nw) {
+    uint32_t res[K];
+    u32x4 nxt[4];
+    for (int j = 0; j < 4; ++j) nxt[j] = NT ? __builtin_nontemporal_load(&w[((c * K) * 4 + j) * 64 + lane]) : w[((c * K) * 4 + j) * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u32x4 raw[4];
+      for (int j = 0; j < 4; ++j) raw[j] = nxt[j];
+      if (k + 1 < K)
+        for (int j = 0; j < 4; ++j) nxt[j] = NT ? __builtin_nontemporal_load(&w[((c * K + k + 1) * 4 + j) * 64 + lane]) : w[((c * K + k + 1) * 4 + j) * 64 + lane];
+      uint32_t a = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a ^= raw[j][0] ^ raw[j][1] ^ raw[j][2] ^ raw[j][3];
+      res[k] = a;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) *(uint32_t*)(st + ((c * K + k) * 64 + lane) * 4) = res[k];
+  }
+}
+
 template <int NV, int WORK, bool NT, bool RUN64>
 __global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ w, uint32_t* __restrict__ out, int64_t nvec) {
   const int lane = threadIdx.x & 63;
@@ -106,6 +134,10 @@ int main() {
       run2("read + 8 B x 16 lanes per 4 KiB", k_read_store<8, 16, false>, grid);
       run2("read + 4 B x 16 lanes per 4 KiB", k_read_store<4, 16, false>, grid);
       run2("read + 8 B x 1 lane per 4 KiB", k_read_store<8, 1, false>, grid);
+      run2("deferred 4 B x 64, K = 4 consecutive steps", k_read_store_deferred<4, true>, grid);
+      run2("deferred 4 B x 64, K = 8", k_read_store_deferred<8, true>, grid);
+      run2("deferred 4 B x 64, K = 16", k_read_store_deferred<16, true>, grid);
+      run2("deferred 4 B x 64, K = 16, plain loads", k_read_store_deferred<16, false>, grid);
     }
   }
   for (int grid : {8192}) {

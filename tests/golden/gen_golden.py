@@ -21,6 +21,10 @@ Files written:
   quant_search.npz      search_datatype (mixed_bitmod / mixed_er / mixed_ea / mixed_ant, 3 and 4 bits) on float16 inputs
   quant_specials.npz    the four headline formats on rows holding +-inf / NaN, rows on one side of zero, all-zero
                         and constant rows, values at the float16 limits (per-channel, g=64, per-tensor)
+  quant_model.npz       quant_model (the _LinearDump wrapper included, quant_weight.py:876-936) on a seeded
+                        nn.Sequential of four float16 nn.Linear: weights before / after, every registered buffer
+                        (bytes, dtype, shape) and the module class names, for int8 / int8_asym / int4_asym /
+                        fp8_e4m3 / fp4 x {per-channel, g=64, per-tensor}
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
@@ -340,6 +344,45 @@ def gen_search():
     print("quant_search.npz", len(arrays), "arrays")
 
 
+QUANT_MODEL_CASES = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp4", 4)]
+QUANT_MODEL_GROUPS = [None, 64, -1]
+
+
+def gen_quant_model():
+    """The reference's quant_model on a small model (time.sleep patched out: it only paces the prints)."""
+    import contextlib
+    import io
+    import torch.nn as nn
+    qw.time.sleep = lambda *_: None
+    out = {}
+    torch.manual_seed(1234)
+    base = nn.Sequential(nn.Linear(256, 128), nn.Linear(128, 256, bias=False), nn.Linear(256, 128), nn.Linear(128, 64)).half()
+    base[2].weight.data[3, 5] = 0.75          # an outlier
+    base[3].weight.data[1] = 0                # a zero row
+    for i, m in enumerate(base):
+        out[f"in/{i}/weight"] = bits16(m.weight.data)
+        out[f"in/{i}/has_bias"] = np.array([m.bias is not None])
+    for dt, bits in QUANT_MODEL_CASES:
+        for gs in QUANT_MODEL_GROUPS:
+            import copy
+            model = copy.deepcopy(base)
+            with contextlib.redirect_stdout(io.StringIO()):
+                qw.quant_model(model, bits, dt, gs)
+            key = f"{dt}/{gs_key(gs)}"
+            out[f"{key}/classes"] = np.array([type(m).__name__ for m in model])
+            for i, m in enumerate(model):
+                out[f"{key}/{i}/weight"] = bits16(m.weight.data)
+                names = sorted(n for n, _ in m.named_buffers())
+                out[f"{key}/{i}/buffers"] = np.array(names)
+                for n in names:
+                    b = getattr(m, n)
+                    out[f"{key}/{i}/{n}/bytes"] = b.contiguous().reshape(-1).view(torch.uint8).numpy().copy()
+                    out[f"{key}/{i}/{n}/dtype"] = np.array([str(b.dtype)])
+                    out[f"{key}/{i}/{n}/shape"] = np.array(list(b.shape), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "quant_model.npz"), **out)
+    print("quant_model.npz", len(out), "arrays")
+
+
 def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -410,6 +453,9 @@ if __name__ == "__main__":
         gen_lut_tables()
         gen_more_formats()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "model":
+        gen_quant_model()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "specials":
         gen_specials()
         sys.exit(0)
@@ -425,6 +471,7 @@ if __name__ == "__main__":
     gen_table_formats()
     gen_search()
     gen_specials()
+    gen_quant_model()
     gen_quant_small()
     gen_exhaustive()
     gen_lut_domain()

@@ -1,0 +1,23 @@
+"""CPU: exhaustive check of the packed float16 division of the statistics kernels (div_pk16 in mq_quant.hip) on
+the whole (float16 value) x (float16 scale >= 2^-15) domain the fast path admits -- 664 M pairs, a few seconds with
+OpenMP (tests/tools/div16_exhaustive.c states what is checked)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_packed_float16_division_is_exact(tmp_path):
+    flags = open("/proc/cpuinfo").read()
+    if " f16c" not in flags or " fma" not in flags:
+        pytest.skip("host CPU lacks F16C/FMA")
+    exe = tmp_path / "div16_exhaustive"
+    subprocess.check_call(["gcc", "-O2", "-mf16c", "-mfma", "-fopenmp", "-ffp-contract=off",
+                           os.path.join(HERE, "tools", "div16_exhaustive.c"), "-o", str(exe), "-lm"])
+    env = dict(os.environ, OMP_NUM_THREADS=str(min(8, os.cpu_count() or 1)))
+    pairs, bad_rint, bad_bits, bad_recip, inexact = map(int, subprocess.check_output([str(exe)], env=env).split())
+    assert pairs > 600_000_000
+    assert bad_rint == 0 and bad_bits == 0 and bad_recip == 0
+    assert inexact == 0   # the emulation of the float16 fma was exact everywhere

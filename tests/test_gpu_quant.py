@@ -449,3 +449,41 @@ def test_statistics_only_mode_equals_general_mode(qa, fmt):
     b_stats = quantize_batch(w3, code, bits, 128, table, deq=False, codes=False, scale=False, seg_sse=True, totals=True)
     torch.testing.assert_close(b_stats.seg_sse, b_full.seg_sse, rtol=1e-6, atol=0)
     torch.testing.assert_close(b_stats.totals, b_full.totals, rtol=5e-7, atol=0)
+
+
+QUANT_MODEL_CASES = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp4", 4)]
+
+
+@pytest.mark.parametrize("case", QUANT_MODEL_CASES, ids=[c[0] for c in QUANT_MODEL_CASES])
+def test_quant_model_reference_fixture(qa, case):
+    """quant_model (weights rewritten in place, every nn.Linear replaced by a _LinearDump carrying weight_q /
+    weight_scale / weight_zp) against what the reference's own quant_model produced for the same seeded model
+    (tests/golden/quant_model.npz, written by gen_golden.py from the imported quant_weight.py:652-706, :876-936):
+    module class names, weights, and every buffer's name, dtype, shape and bytes."""
+    import contextlib
+    import io
+    import torch.nn as nn
+    datatype, bits = case
+    z = gu.npz("quant_model.npz")
+    for gs in (None, 64, -1):
+        layers = []
+        for i, (fin, fout) in enumerate(((256, 128), (128, 256), (256, 128), (128, 64))):
+            m = nn.Linear(fin, fout, bias=bool(z[f"in/{i}/has_bias"][0])).half()
+            m.weight.data = torch.from_numpy(z[f"in/{i}/weight"].view(np.int16).copy()).view(torch.float16)
+            layers.append(m)
+        model = nn.Sequential(*layers).cuda()
+        with contextlib.redirect_stdout(io.StringIO()):
+            qa.quant_weight.quant_model(model, bits, datatype, gs)
+        key = f"{datatype}/{gu.gs_key(gs)}"
+        assert [type(m).__name__ for m in model] == list(z[f"{key}/classes"]), key
+        for i, m in enumerate(model):
+            what = (key, i)
+            assert isinstance(m, nn.Linear)
+            assert np.array_equal(bits16(m.weight.data), z[f"{key}/{i}/weight"]), (what, "weight")
+            assert sorted(n for n, _ in m.named_buffers()) == list(z[f"{key}/{i}/buffers"]), what
+            for n in z[f"{key}/{i}/buffers"]:
+                b = getattr(m, str(n))
+                assert str(b.dtype) == z[f"{key}/{i}/{n}/dtype"][0], (what, n, "dtype")
+                assert list(b.shape) == list(z[f"{key}/{i}/{n}/shape"]), (what, n, "shape")
+                got = b.contiguous().reshape(-1).view(torch.uint8).cpu().numpy()
+                assert np.array_equal(got, z[f"{key}/{i}/{n}/bytes"]), (what, n, "bytes")

@@ -172,3 +172,33 @@ def test_layer_record_explicit_list_table(oracle):
     assert abs(rec[3] - st["mse_rep"]) <= 1e-6 * st["mse_rep"] and abs(rec[4] - st["mse_p99"]) <= 1e-6 * st["mse_p99"]
     both = report.model_records([w.cuda(), w.cuda()], "flint4", 4, 64).cpu().numpy()
     assert np.array_equal(both[0], rec) and np.array_equal(both[1], rec)
+
+
+def test_orderings_the_reference_reports_show():
+    """A sanity pin, NOT a bit-wise one: the only error-analysis numbers the reference holds are its two CSV reports
+    on an OPT-1.3B weight (MSE&P99/channel_mse_report.csv:2-5, group_mse_report.csv:2-5: 2048 channels, 16 groups
+    of 128 per channel), whose weights are not available.  On a seeded 2048 x 2048 N(0, 0.02^2) float16 tensor the
+    same relations must hold: tensor MSE int8_asym < int8 < fp8_e3m4 < fp8_e4m3 at both granularities, per-group
+    below per-channel for every format, mse_rep = mse_tensor to float32 rounding (the CSV rows agree to 3e-8
+    ... 3e-7), and mse_p99 above mse_rep."""
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(2048)
+    w = (torch.randn(2048, 2048, generator=g, device="cuda") * 0.02).half()
+    fmts = ["int8_asym", "int8", "fp8_e3m4", "fp8_e4m3"]
+    mse = {}
+    for gs in (None, 128):
+        recs = report.model_records([w], fmts[0], 8, gs)   # (the sweep path)
+        for f in fmts:
+            r = report.layer_record(w, f, 8, gs, form="single").cpu().numpy()
+            if f == fmts[0]:
+                assert np.array_equal(r, recs[0].cpu().numpy())
+            mse_tensor, mse_rep, mse_p99 = r[1] / r[0], r[3], r[4]
+            mse[(f, gs)] = mse_tensor
+            assert abs(mse_rep - mse_tensor) <= 1e-6 * mse_tensor, (f, gs)
+            assert mse_p99 > mse_rep, (f, gs)
+        vals = [mse[(f, gs)] for f in fmts]
+        assert vals == sorted(vals) and len(set(vals)) == 4, (gs, vals)
+    for f in fmts:
+        assert mse[(f, 128)] < mse[(f, None)], f
+    # the magnitudes are those of the reports (same formats, a weight of similar scale): within a factor 10
+    assert 1e-9 < mse[("int8_asym", 128)] < 1e-7 and 1e-8 < mse[("fp8_e4m3", None)] < 1e-6

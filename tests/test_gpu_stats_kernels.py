@@ -170,3 +170,18 @@ def test_segment_mse_float32_form(dt):
         check(a.seg_mse, b.seg_sse, 24 * 256 if gs == -1 else (gs or 256), f"table {gs}")
     with pytest.raises(ValueError):
         quantize(w[0], _lib.INT_SYM, 8, 64, seg_sse=True, seg_mse=True)
+
+
+def test_packed_division_selfcheck_on_device():
+    """mq_selfcheck_div16: the packed float16 division of the statistics kernels against the float32 division of
+    the general kernels, every admitted (scale, value) pair, with this device's own reciprocal instruction (the CPU
+    enumeration with emulated float16 arithmetic is tests/test_div16_exhaustive.py)."""
+    import ctypes
+    from quantization_amd import _lib
+    L = _lib.lib()
+    L.mq_selfcheck_div16.restype = ctypes.c_int
+    L.mq_selfcheck_div16.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    counts = torch.full((3,), -1, dtype=torch.int64, device="cuda")
+    _lib.check(L.mq_selfcheck_div16(counts.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    pairs, bad_rint, bad_bits = counts.cpu().tolist()
+    assert pairs > 1_200_000_000 and bad_rint == 0 and bad_bits == 0, (pairs, bad_rint, bad_bits)
