@@ -43,9 +43,14 @@ def main():
         rows[k] = {"launches": len(fetch.get(k, [])), "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
                    "hbm_bytes": 2 * f * 1024 + w * 1024}
         print(f"{k:62s} n={rows[k]['launches']:4d} read {2*f*1024/1e6:10.1f} MB  write {w*1024/1e6:10.1f} MB")
-    quant = [v for k, v in rows.items() if "k_quant" in k and "[sampling pass]" not in k
-             and ("[full pass]" in k or not any("[full pass]" in q for q in rows))]
-    per_launch = sum(v["hbm_bytes"] for v in quant) / max(1, len(quant))
+    # the dominant kernel of the workload: the statistics-only kernels of the model sweeps, else the full quantize
+    # passes; bytes per launch averaged over every such launch (as bench.py averages its durations)
+    if any("k_stats_" in k for k in rows):
+        quant = [v for k, v in rows.items() if "k_stats_" in k]
+    else:
+        quant = [v for k, v in rows.items() if "k_quant" in k and "[sampling pass]" not in k
+                 and ("[full pass]" in k or not any("[full pass]" in q for q in rows))]
+    per_launch = sum(v["hbm_bytes"] * v["launches"] for v in quant) / max(1, sum(v["launches"] for v in quant))
     out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
     data[workload] = round(per_launch)
