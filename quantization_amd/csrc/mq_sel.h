@@ -16,6 +16,7 @@
 #define SEL_CHUNK_LINES 32   // one 256-byte line of every 32 is sampled
 #define SEL_BR_MIN_N (1 << 21)
 #define SEL_FEED_HASH 2048   // LDS table of a feeding kernel: keys[2048] + counts[2048] = 16 KiB
+#define SEL_CAND_MAX (SEL_BR_BINS * 65536)  // capacity of the candidate list that overlays br_fine
 
 struct SelState {
   uint64_t prefix[2];  // resolved high bits of the two keys, left-aligned in 63 bits
@@ -37,7 +38,10 @@ struct SelWs {
   uint32_t br_shift;         // bit patterns per bracket-histogram entry = 2^br_shift (0 for <= 16 bins)
   unsigned long long below;  // exact number of elements under the bracket
   uint32_t ref_base[2];      // ok == 2: first bit pattern of the entry holding rank r ...
-  uint32_t pad1[2];
+  uint32_t cand_n;           // fed selection with a wide bracket (br_shift > 0): br_fine holds the bit patterns of
+                             // the values inside the bracket, as a list of cand_n entries (may pass SEL_CAND_MAX:
+                             // then the list overflowed and is not used)
+  uint32_t pad1;
   unsigned long long ref_rank[2];  // ... and the rank inside that entry
   uint32_t refine[2][16];    // counts per bit pattern inside those entries (filled by the refining pass)
   uint32_t pad[8];
@@ -83,6 +87,7 @@ struct SelFeed {
   lds_u32* hcnt;  // LDS [SEL_FEED_HASH]
   SelWs* ws;
   uint32_t lo, nb, shift;  // bracket (count mode)
+  uint32_t cand_words;     // wide bracket: LDS words per wave of the candidate staging area
   uint32_t below;   // this lane's count of values under the bracket
   int mode;
   uint16_t* samples;     // sample mode: where this array's samples go
@@ -104,12 +109,14 @@ __device__ __forceinline__ void sel_feed_init(SelFeed& f, SelWs* ws, uint32_t* l
   f.lo = 0;
   f.nb = 0;
   f.shift = 0;
+  f.cand_words = 0;
   f.below = 0;
   if (mode == SEL_FEED_COUNT) {
     for (int i = threadIdx.x; i < 2 * SEL_FEED_HASH; i += blockDim.x) lds[i] = 0;
     f.lo = ws->br_lo;
     f.nb = ws->br_nb;
     f.shift = ws->br_shift;
+    f.cand_words = (2 * SEL_FEED_HASH) / (blockDim.x >> 6);
     __syncthreads();
   }
 }
@@ -140,6 +147,28 @@ __device__ __forceinline__ void sel_feed_add(SelFeed& f, uint32_t key, uint32_t*
   }
 }
 
+// Wide bracket (more than SEL_BR_BINS level-0 bins: heavy-tailed data): no histogram could hold every bit pattern
+// of the bracket, but the values inside it are still only the fraction of a percent that the sample ranks span.
+// Their exact bit patterns are kept: each wave stages them in its slice of the LDS area (word 0: count) and
+// appends full stages to the list in ws->br_fine with one global atomic; a small kernel then selects among the
+// list (k_sel_cand), so the stored array is not read again.
+__device__ __forceinline__ void sel_feed_cand_flush(SelFeed& f) {  // whole wave, converged
+  lds_u32* reg = f.hkey + (threadIdx.x >> 6) * f.cand_words;
+  const uint32_t cnt = reg[0];
+  if (cnt == 0u) return;
+  uint32_t base = 0u;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(&f.ws->cand_n, cnt);
+  base = __builtin_amdgcn_readfirstlane(base);
+  for (uint32_t i = threadIdx.x & 63; i < cnt; i += 64)
+    if (base + i < (uint32_t)SEL_CAND_MAX) f.ws->br_fine[base + i] = reg[1 + i];
+  if ((threadIdx.x & 63) == 0) reg[0] = 0u;
+}
+__device__ __forceinline__ void sel_feed_cand_add(SelFeed& f, uint32_t bits) {
+  lds_u32* reg = f.hkey + (threadIdx.x >> 6) * f.cand_words;
+  const uint32_t pos = __hip_atomic_fetch_add(&reg[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  reg[1 + pos] = bits;  // (room for a whole vector of every lane was made before the vector: sel_feed8)
+}
+
 // Eight float32 values (their sign is ignored) of one lane, elements e0 .. e0 + 7 of the array.
 // Sample mode: the top 16 bits of each go to the dense sample array with one 16-byte store (a small kernel
 // histograms them afterwards: a direct LDS histogram is far cheaper than table inserts for EVERY value).
@@ -164,6 +193,12 @@ __device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0
     f.below += a[i] < lo_bits ? 1u : 0u;
     mask |= (a[i] - lo_bits < span ? 1u : 0u) << i;  // the subtraction wraps for values under the bracket
   }
+  const bool wide = f.shift != 0u;  // (uniform over the workgroup: a property of the tensor's bracket)
+  if (wide && __builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+    // the wave is about to add up to 8 x 64 entries: empty the stage if they might not fit
+    lds_u32* reg = f.hkey + (threadIdx.x >> 6) * f.cand_words;
+    if (reg[0] + 512u > f.cand_words - 1u) sel_feed_cand_flush(f);
+  }
 #pragma unroll 1
   while (mask) {
     const int i = __builtin_ctz(mask);
@@ -173,7 +208,8 @@ __device__ __forceinline__ void sel_feed8(SelFeed& f, const float* e, int64_t e0
                    p3 = (i & 1) ? a[7] : a[6];
     const uint32_t q0 = (i & 2) ? p1 : p0, q1 = (i & 2) ? p3 : p2;
     const uint32_t bits = (i & 4) ? q1 : q0;
-    sel_feed_add(f, (bits - lo_bits) >> f.shift, f.ws->br_fine, f.ws->br_coarse);
+    if (wide) sel_feed_cand_add(f, bits);
+    else sel_feed_add(f, bits - lo_bits, f.ws->br_fine, f.ws->br_coarse);
   }
 }
 
@@ -191,6 +227,10 @@ __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
     unsigned long long t = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += wcnt[i];
     if (t) atomicAdd(&f.ws->below, t);
+  }
+  if (f.shift != 0u) {  // wide bracket: the LDS area holds the waves' candidate stages, not a table
+    sel_feed_cand_flush(f);
+    return;
   }
   // table entries -> registers, then the table's memory becomes the coarse counters of this workgroup
   uint32_t k[8], c[8];
@@ -213,7 +253,7 @@ __device__ __forceinline__ void sel_feed_flush(SelFeed& f) {
     }
   }
   __syncthreads();
-  const uint32_t ncoarse = ((f.nb << 16) >> f.shift) >> 8;  // <= SEL_BR_BINS * 256
+  const uint32_t ncoarse = (f.nb << 16) >> 8;  // <= SEL_BR_BINS * 256
   for (uint32_t i = threadIdx.x; i < ncoarse; i += blockDim.x)
     if (lco[i]) atomicAdd(&f.ws->br_coarse[i], lco[i]);
 }

@@ -590,7 +590,8 @@ __global__ __launch_bounds__(256) void k_sel_bracket(const SelBatch b) {
 
 // Both ranks inside the bracket -> exact values, interpolation, ok = 1; with a coarse bracket histogram
 // (br_shift > 0) -> the entries holding them, ok = 2 (the refining pass finishes).
-__global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+__global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, const SelRanks rk, FinishArgs fin,
+                                                          int cand_mode) {
   const uint64_t k0 = rk.k0[blockIdx.x], k1 = rk.k1[blockIdx.x];
   __shared__ uint64_t wsum[4];
   __shared__ uint32_t sh_bin;
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
   SelWs* ws = batch_ws(b, blockIdx.x);
   if (ws->br_nb == 0) return;
   const uint32_t shift = ws->br_shift;
+  if (cand_mode && shift) return;  // a feeding kernel kept this bracket's values as a list: k_sel_cand
   const uint32_t entries = (ws->br_nb << 16) >> shift;
   const uint32_t nchunks = (entries + 65535u) >> 16;  // chunks of 65536 histogram entries
   if (threadIdx.x == 0) { sh_bin = 0; sh_rank = 0; tot[0] = 0; }
@@ -636,6 +638,98 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
     finish_store(fin, blockIdx.x, (uint64_t)bits[0] << 32, (uint64_t)bits[1] << 32, rk.gamma[blockIdx.x]);
     ws->st.prefix[0] = (uint64_t)bits[0] << 32;
     ws->st.prefix[1] = (uint64_t)bits[1] << 32;
+    ws->ok = 1;
+  }
+}
+
+// ---- wide brackets of a fed selection: select among the kept values -----------------------------------------
+// One 1024-thread workgroup per array whose feeding kernel left the bit patterns of the values inside the bracket
+// as a list (SelWs::cand_n entries in br_fine, see sel_feed_cand_add): the wanted ranks, less the count below
+// the bracket, are resolved among the list in two sweeps of 12 bits over the patterns' offsets from the bracket's
+// first pattern (the list is a few hundred KiB and stays in L2).  Slices with a narrow bracket, a missed bracket or an overflowed list are left alone (the
+// exact route over the stored array, enqueued behind, handles whatever has ok == 0).
+__global__ __launch_bounds__(1024) void k_sel_cand(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+  constexpr int BITS = 12, NB = 1 << BITS;  // keys relative to the bracket's first pattern: < 2^24, two sweeps
+  __shared__ uint32_t hist[2][NB];
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t s_prefix[2];
+  __shared__ uint64_t s_rank[2];
+  SelWs* ws = batch_ws(b, blockIdx.x);
+  if (ws->br_nb == 0 || ws->br_shift == 0 || ws->ok) return;
+  const uint64_t n = ws->cand_n, below = ws->below;
+  const uint64_t k0 = rk.k0[blockIdx.x], k1 = rk.k1[blockIdx.x];
+  if (n > (uint64_t)SEL_CAND_MAX || k0 < below || k1 >= below + n) return;
+  const uint32_t* x = ws->br_fine;
+  const uint32_t lo_bits = ws->br_lo << 16;  // (br_nb <= SEL_BR_MAX_BINS = 256 bins of 2^16 patterns)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    s_prefix[0] = s_prefix[1] = 0;
+    s_rank[0] = k0 - below;
+    s_rank[1] = k1 - below;
+  }
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    const int shift = sweep == 0 ? BITS : 0;
+    for (int i = threadIdx.x; i < 2 * NB; i += blockDim.x) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t p0 = s_prefix[0], p1 = s_prefix[1];
+    const bool same = p0 == p1;
+    const uint32_t himask = sweep == 0 ? 0u : ~((uint32_t)NB - 1u);
+    auto put = [&](uint32_t bits) {
+      const uint32_t key = bits - lo_bits;
+      const uint32_t d = (key >> shift) & (NB - 1);
+      if ((key & himask) == p0) atomicAdd(&hist[0][d], 1u);
+      if (!same && (key & himask) == p1) atomicAdd(&hist[1][d], 1u);
+    };
+    // 16-byte loads, four in flight per thread (one workgroup walks the list: the loop is bound by load latency)
+    const uint64_t nvec = n / 4;
+    for (uint64_t v0 = threadIdx.x; v0 < nvec; v0 += 4 * blockDim.x) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t v = v0 + (uint64_t)u * blockDim.x;
+        raw[u] = v < nvec ? reinterpret_cast<const u32x4*>(x)[v] : u32x4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (v0 + (uint64_t)u * blockDim.x >= nvec) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) put(raw[u][j]);
+      }
+    }
+    for (uint64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) put(x[i]);
+    __syncthreads();
+    for (int r = 0; r < 2; ++r) {  // every thread owns four consecutive bins
+      const uint32_t* h = hist[(same || r == 0) ? 0 : 1];
+      const uint64_t want = s_rank[r];
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = h[4 * threadIdx.x + j];
+      const uint32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+      uint32_t inc = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      __syncthreads();
+      if (lane == 63) wtot[wv] = inc;
+      __syncthreads();
+      uint64_t before = inc - mine;
+      for (int w = 0; w < wv; ++w) before += wtot[w];
+      if (want >= before && want < before + mine) {
+        int j = 0;
+        while (want >= before + c[j]) { before += c[j]; ++j; }
+        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint32_t)(4 * threadIdx.x + j) << shift);
+        s_rank[r] = want - before;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t a = (uint64_t)(s_prefix[0] + lo_bits) << 32, c = (uint64_t)(s_prefix[1] + lo_bits) << 32;
+    finish_store(fin, blockIdx.x, a, c, rk.gamma[blockIdx.x]);
+    ws->st.prefix[0] = a;
+    ws->st.prefix[1] = c;
     ws->ok = 1;
   }
 }
@@ -692,14 +786,21 @@ extern "C" int mq_percentile_index(int32_t dtype, int64_t n, double pct, int64_t
   return MQ_OK;
 }
 
+#define SEL_FEED_SIGMAS 16.0
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
-// Sample ranks 8 standard deviations either side of the wanted quantile among the m sampled elements of an
-// array of n; false when the array is too small or the quantile too near an end for the bracket route.
-static bool bracket_ranks_m(int64_t n, int64_t m, int64_t k0, int64_t k1, double* r_lo, double* r_hi) {
+// Sample ranks `sigmas` binomial standard deviations either side of the wanted quantile among the m sampled
+// elements of an array of n; false when the array is too small or the quantile too near an end for the bracket
+// route.  The samples are clusters of consecutive elements, not independent draws, so the sample quantile
+// scatters more than the binomial figure: by a factor 2 .. 2.6 for the 64-element lines of a stored |error|
+// array of normal weights (8 sigmas are used there), by 3.5 .. 5 (11 at the worst of 20 trials) for the
+// 512-element runs a feeding quantize kernel samples from Student-t weights, whose |error| level is a property
+// of the whole group (16 sigmas there; a bracket that misses is only a lost shortcut, the exact route runs).
+static bool bracket_ranks_m(int64_t n, int64_t m, int64_t k0, int64_t k1, double* r_lo, double* r_hi,
+                            double sigmas = 8.0) {
   if (n < SEL_BR_MIN_N || m < 1) return false;
   const double frac = (double)m / (double)n, p = ((double)k0 + 0.5) / (double)n;
-  const double margin = 8.0 * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
+  const double margin = sigmas * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
   *r_lo = __builtin_floor((double)k0 * frac) - margin;
   *r_hi = __builtin_ceil((double)k1 * frac) + margin;
   return *r_lo >= 0.0 && *r_hi <= (double)(m - 1);
@@ -861,7 +962,7 @@ static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t
     nb = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
     cap = 2048 / c < 16 ? 16 : 2048 / c;
     hipLaunchKernelGGL(k_sel_bracket, dim3((unsigned)(nb > cap ? cap : nb), (unsigned)c), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, rk, fin_last);
+    hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, rk, fin_last, 0);
     MQ_HIP(hipGetLastError());
   }
   const int guard = bracket ? 1 : 0;  // the exact route returns at once for slices the bracket resolved
@@ -975,7 +1076,7 @@ bool sel_feed_eligible(int64_t n, int64_t m, double pct) {
   int64_t k0, k1;
   double g, lo, hi;
   if (mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &g)) return false;
-  return bracket_ranks_m(n, m, k0, k1, &lo, &hi);
+  return bracket_ranks_m(n, m, k0, k1, &lo, &hi, SEL_FEED_SIGMAS);
 }
 
 static void feed_batch(void* ws, int count, const void* const* xs, int64_t n, SelBatch* b) {
@@ -1004,7 +1105,7 @@ int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sampl
   double g, lo, hi;
   int rc = mq_percentile_index(MQ_F32, n, pct, &k0, &k1, &g);
   if (rc) return rc;
-  if (!bracket_ranks_m(n, m, k0, k1, &lo, &hi)) return MQ_ERR_ARG;
+  if (!bracket_ranks_m(n, m, k0, k1, &lo, &hi, SEL_FEED_SIGMAS)) return MQ_ERR_ARG;
   SelBatch b;
   feed_batch(ws, count, nullptr, n, &b);
   SelSampleRanks sr = {};
@@ -1037,7 +1138,8 @@ int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, doubl
     rk.k1[i] = (uint64_t)k1;
   }
   FinishArgs fin_last = {MQ_F32, static_cast<char*>(out), nullptr};
-  hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)count), dim3(256), 0, st, b, rk, fin_last);
+  hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)count), dim3(256), 0, st, b, rk, fin_last, 1);
+  hipLaunchKernelGGL(k_sel_cand, dim3((unsigned)count), dim3(1024), 0, st, b, rk, fin_last);
   MQ_HIP(hipGetLastError());
   for (int level = 0; level <= 1; ++level) {  // the exact route, skipped per slice when the bracket held
     int rc = launch_accumulate(b, count, n, MQ_F32, level, st, 1);

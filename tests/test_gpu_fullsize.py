@@ -80,3 +80,26 @@ def test_llama_sized_rows_vs_oracle(oracle):
             assert np.array_equal(bits16(res.scale), exp["scale"]), (cols, table, code)
             e = exp["v16"].view(np.float16).astype(np.float32) - exp["deq"].view(np.float16).astype(np.float32)
             np.testing.assert_allclose(res.seg_sse.cpu().numpy(), (e * e).astype(np.float64).sum(1), rtol=2e-7)
+
+
+@pytest.mark.parametrize("gs", [32, 128])
+def test_c2_sized_batch_heavy_tails(gs):
+    """Student-t (3 degrees of freedom) weights: the |error| distribution around its P99 spans more level-0 bins
+    than a bracket histogram holds, so the quantize pass keeps the bit patterns of the values inside the bracket
+    as a list and the percentile is selected among them (k_sel_cand).  Bit for bit numpy's percentile of the dump,
+    for 99 and for quantiles whose brackets are wider still."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize_batch
+    g = torch.Generator(device="cuda").manual_seed(77)
+    B = 4
+    x = torch.randn(B, 4096, 4096, generator=g, device="cuda")
+    chi = sum(torch.randn(B, 4096, 4096, generator=g, device="cuda") ** 2 for _ in range(3))
+    w = (x / torch.sqrt(chi / 3) * 0.02).half()
+    for pct in (99, 99.9, 90):
+        res = quantize_batch(w, _lib.INT_ASYM, 8, gs, None, deq=True, codes=False, scale=False, abs_err=torch.float32,
+                             p99=pct)
+        err = (w.float() - res.deq.float()).abs()
+        assert torch.equal(res.abs_err, err)
+        for k in range(B):
+            want = np.percentile(err[k].cpu().numpy().ravel(), pct)
+            assert res.abs_p99[k].cpu().numpy().view(np.uint32) == want.view(np.uint32), (gs, pct, k)
