@@ -86,12 +86,14 @@ __device__ __forceinline__ SegT tbl_seg_params(const TableParams& p, uint32_t am
     s = s > 1e4f ? 1e4f : s;
     sp.s = s;
   } else {
-    // 2^floor(log2(amax)): the exponent of amax (torch computes log2 in float32; for the float16- or
-    // bfloat16-valued maxima of real weights the rounding of log2 never reaches the next integer)
+    // 2^floor(log2(amax)) with log2 in float32, as torch computes it (quant_weight.py:361-362): for a float32
+    // maximum a step or two under a power of two the float32 logarithm rounds UP to the integer (7.9999995 -> 3.0),
+    // so the exponent field of amax is not enough.  float32(log2 in float64) is the correctly rounded float32
+    // logarithm, which is what torch's log2 returns next to powers of two (pinned by the pow2edge golden case).
     const float a = f_from_bits(amax_bits);
     if (a == 0.0f) sp.s = 0.0f;                       // log2(0) = -inf, 2^-inf = 0
     else if (amax_bits >= 0x7f800000u) sp.s = a;      // inf stays inf, NaN stays NaN
-    else sp.s = ldexpf(1.0f, ilogbf(a));
+    else sp.s = ldexpf(1.0f, (int)floorf((float)log2((double)a)));
   }
   return sp;
 }

@@ -202,10 +202,24 @@ def gen_table_formats():
     bits = np.arange(65536, dtype=np.uint16).reshape(256, 256)
     allf16 = torch.from_numpy(bits.view(np.int16).copy()).view(torch.float16)
     inputs["exhaustive.f16"] = torch.where(torch.isfinite(allf16), allf16, torch.zeros_like(allf16))
+    # float32 weights whose group maxima sit 1 .. 3 float32 steps under a power of two: there float32 log2 rounds
+    # up to the integer and quant_mx's floor(log2(max)) is one more than the exponent field of max (MX only)
+    edge = (torch.randn(8, 512, generator=gen) * 0.3).float().clamp(-0.9, 0.9)
+    for r in range(8):
+        for gidx in range(16):
+            k = (r * 16 + gidx) % 25 - 14
+            a = np.float32(2.0 ** k)
+            for _ in range(1 + (r + gidx) % 3):
+                a = np.nextafter(a, np.float32(0))
+            edge[r, gidx * 32: (gidx + 1) * 32] *= float(2.0 ** k)
+            edge[r, gidx * 32 + (5 * gidx + r) % 32] = float(a) * (-1.0 if (r + gidx) % 2 else 1.0)
+    inputs["pow2edge.f32"] = edge
     for name, w in inputs.items():
         arrays[f"in/{name}"] = w.numpy().copy() if name.endswith(".f32") else bits16(w)
 
     def groups(name, fmt):
+        if name.startswith("pow2edge"):
+            return []
         if name.startswith("exhaustive"):
             return [None] if fmt in ("flint4", "fp3_ea_neg", "flint5", "fp8_e5m2") else []
         return [None, 64, -1]
