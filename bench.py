@@ -253,7 +253,7 @@ class Workload:
         """All fused quantize launches of the step, then ONE set of select launches per dtype for the P99s of
         every tensor of the step (the chains of short kernels run once per step, not once per batch)."""
         import torch
-        from quantization_amd.error_metrics import percentile_multi
+        from quantization_amd.error_metrics import percentile_rows
         from quantization_amd.fused import QuantResult, quantize_batch
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
@@ -279,10 +279,7 @@ class Workload:
         # mean of a tensor's per-vector MSE list = its tensor MSE (all vectors have one length); the P99 is selected
         # on the float32 list entries and interpolated in float64, as np.percentile of the scripts' float64 list
         rec[:, 2] = self.totals[:, 0] / self.numel
-        vecs = []
-        for res in results:
-            vecs += [res.seg_mse[i] for i in range(res.seg_mse.shape[0])]
-        rec[:, 3] = percentile_multi(vecs, 99, nan_check=False, wide=True)
+        rec[:, 3] = percentile_rows([res.seg_mse for res in results], 99, wide=True)
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
         return rec

@@ -165,6 +165,38 @@ def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: b
     return out
 
 
+@torch.no_grad()
+def percentile_rows(mats: Sequence[torch.Tensor], pct: float = 99.0, wide: bool = False) -> torch.Tensor:
+    """np.percentile(row, pct) for every row of every 2-D tensor of `mats` (one dtype; rows contiguous, 16-byte
+    aligned, possibly padded: only stride(1) == 1 is required), results concatenated in order.  percentile_multi
+    without a tensor object per row: a model sweep selects from hundreds of per-layer lists per pass.  No NaN
+    check (as percentile_multi(nan_check=False))."""
+    if not mats:
+        raise ValueError("percentile_rows() needs at least one tensor")
+    dtype, dev = mats[0].dtype, mats[0].device
+    code, rdt = _sel_dtype(dtype, wide)
+    ptrs, ns = [], []
+    for m in mats:
+        if m.dim() != 2 or m.dtype != dtype or m.device != dev or not m.is_cuda or m.stride(1) != 1:
+            raise ValueError("percentile_rows(): 2-D ROCm tensors of one dtype with contiguous rows")
+        if m.shape[1] == 0:
+            raise IndexError("percentile of an empty array")
+        base, step = m.data_ptr(), m.stride(0) * m.element_size()
+        if base % 16 or (step % 16 and m.shape[0] > 1):
+            raise ValueError("percentile_rows(): rows must start on 16-byte boundaries")
+        ptrs += [base + i * step for i in range(m.shape[0])]
+        ns += [m.shape[1]] * m.shape[0]
+    B = len(ptrs)
+    L = _bind()
+    out = torch.empty(B, dtype=rdt, device=dev)
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
+        st = L.mq_percentile_multi((ctypes.c_void_p * B)(*ptrs), (ctypes.c_int64 * B)(*ns), B, code, float(pct),
+                                   out.data_ptr(), None, ws.data_ptr(), ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return out
+
+
 def true_div(x: torch.Tensor, d) -> torch.Tensor:
     """x / d as an IEEE division per element.  (torch turns `tensor / python_scalar` on the device into a
     multiplication by the rounded reciprocal, which is off by one ulp for some elements.)"""

@@ -260,17 +260,34 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
             res.totals.zero_()
         return res
 
-    def at(t, i):
-        return None if t is None else t.data_ptr() + i * t.stride(0) * t.element_size()
+    def span(t):  # (address of slice 0, bytes between slices)
+        return (None, 0) if t is None else (t.data_ptr(), t.stride(0) * t.element_size())
 
     items = (_QuantItem * B)()
     aed = _lib.F16 if abs_err == torch.float16 else _lib.F32
+    seg_flag = int(bool(seg_mse))
+    (p_deq, s_deq), (p_codes, s_codes), (p_scale, s_scale), (p_zp, s_zp) = span(b_deq), span(b_codes), span(b_scale), span(b_zp)
+    (p_abs, s_abs), (p_seg, s_seg), (p_tot, s_tot) = span(b_abs), span(b_mse if seg_mse else b_sse), span(b_tot)
     for i in range(B):
-        items[i].w = tensors[i].data_ptr()
-        items[i].out = _lib.QuantOut(deq=at(b_deq, i), codes=at(b_codes, i), scale=at(b_scale, i),
-                                     zero_point=at(b_zp, i), abs_err=at(b_abs, i), abs_err_dtype=aed,
-                                     seg_mse_f32=int(bool(seg_mse)), seg_sse=at(b_mse if seg_mse else b_sse, i),
-                                     totals=at(b_tot, i))
+        it = items[i]
+        it.w = tensors[i].data_ptr()
+        o = it.out
+        if p_deq is not None:
+            o.deq = p_deq + i * s_deq
+        if p_codes is not None:
+            o.codes = p_codes + i * s_codes
+        if p_scale is not None:
+            o.scale = p_scale + i * s_scale
+        if p_zp is not None:
+            o.zero_point = p_zp + i * s_zp
+        if p_abs is not None:
+            o.abs_err = p_abs + i * s_abs
+        o.abs_err_dtype = aed
+        o.seg_mse_f32 = seg_flag
+        if p_seg is not None:
+            o.seg_sse = p_seg + i * s_seg
+        if p_tot is not None:
+            o.totals = p_tot + i * s_tot
     L_ = _lib.lib()
     if not getattr(L_, "_batch_bound", False):
         L_.mq_quantize_batch_workspace_bytes.restype = ctypes.c_size_t

@@ -8,7 +8,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .error_metrics import error_stats, percentile, percentile_multi, true_div
+from .error_metrics import error_stats, percentile, percentile_rows, true_div
 from .fused import LUT_FORMATS, TABLE_LISTS, quantize, quantize_batch, quantize_table
 
 MULTI_COLUMNS = ["initializer", "datatype", "granularity", "bits", "mse_tensor", "mse_rep", "mse_p99"]
@@ -140,9 +140,9 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
                 res._bufs.pop("abs_err", None)   # the |err| scratch of this launch is free for the next one
             keep.append(res)
             vec_rows += sel
-            vecs += list(res.seg_mse.unbind(0))
-    p99v = torch.cat([percentile_multi(vecs[lo:lo + 4096], pct, nan_check=False, wide=True)
-                      for lo in range(0, len(vecs), 4096)])
+            if return_vecs:
+                vecs += list(res.seg_mse.unbind(0))
+    p99v = percentile_rows([r.seg_mse for r in keep], pct, wide=True)
     host = torch.tensor([[float(weights[i].numel()), float(i)] for i in vec_rows], dtype=torch.float64).to(dev)
     numel, tot = host[:, 0], torch.cat(tots)
     mse = tot[:, 0] / numel

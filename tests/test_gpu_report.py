@@ -202,3 +202,20 @@ def test_orderings_the_reference_reports_show():
         assert mse[(f, 128)] < mse[(f, None)], f
     # the magnitudes are those of the reports (same formats, a weight of similar scale): within a factor 10
     assert 1e-9 < mse[("int8_asym", 128)] < 1e-7 and 1e-8 < mse[("fp8_e4m3", None)] < 1e-6
+
+
+def test_percentile_rows_equals_numpy():
+    from quantization_amd import error_metrics as em
+    rng = np.random.default_rng(5)
+    a = np.abs(rng.standard_normal((5, 4096))).astype(np.float32)
+    b = np.abs(rng.standard_normal((3, 50000))).astype(np.float32)
+    pad = torch.zeros(4, 1008, dtype=torch.float32, device="cuda")          # padded rows: a [:, :1001] view
+    c = np.abs(rng.standard_normal((4, 1001))).astype(np.float32)
+    pad[:, :1001] = torch.from_numpy(c).cuda()
+    got = em.percentile_rows([torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), pad[:, :1001]], 99, wide=True)
+    want = np.concatenate([np.percentile(x.astype(np.float64), 99, axis=1) for x in (a, b, c)])
+    assert got.dtype == torch.float64 and got.cpu().numpy().tobytes() == want.tobytes()
+    got32 = em.percentile_rows([torch.from_numpy(a).cuda()], 50)
+    assert got32.cpu().numpy().tobytes() == np.percentile(a, 50, axis=1).astype(np.float32).tobytes()
+    with pytest.raises(ValueError):
+        em.percentile_rows([torch.from_numpy(a).cuda()[:, 1:]], 99)        # rows off the 16-byte grid
