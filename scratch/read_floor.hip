@@ -65,13 +65,16 @@ __global__ __launch_bounds__(256) void k_read_store_deferred(const u32x4* __rest
   }
 }
 
-template <int NV, int WORK, bool NT, bool RUN64>
+// MAP 0: lane l reads vector j * 64 + l (1 KiB per wave instruction); 1: lane l reads the 64-byte run l;
+// 2: lane a + 16 i reads vector j * 64 + 4 a + i (the same 1 KiB per instruction, lanes permuted so that the four
+// vectors of a 64-byte run sit 16 lanes apart: a 4 x 4 transpose by v_permlane16/32_swap then gives each lane a run)
+template <int NV, int WORK, bool NT, int MAP>
 __global__ __launch_bounds__(256) void k_read(const u32x4* __restrict__ w, uint32_t* __restrict__ out, int64_t nvec) {
   const int lane = threadIdx.x & 63;
   const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
   const int64_t tiles = nvec / (64 * NV);
   auto ld = [&](int64_t t, int j) {
-    const int64_t v = RUN64 ? (t * 64 + lane) * NV + j : (t * NV + j) * 64 + lane;
+    const int64_t v = MAP == 1 ? (t * 64 + lane) * NV + j : MAP == 2 ? (t * NV + j) * 64 + 4 * (lane & 15) + (lane >> 4) : (t * NV + j) * 64 + lane;
     return NT ? __builtin_nontemporal_load(&w[v]) : w[v];
   };
   u32x4 nxt[NV];
@@ -146,6 +149,11 @@ int main() {
     run("NV8 contiguous", k_read<8, 0, false, false>, grid);
     run("NV2 contiguous", k_read<2, 0, false, false>, grid);
     run("NV4 64-byte runs per lane", k_read<4, 0, false, true>, grid);
+    run("NV4 permuted lanes (16 apart)", k_read<4, 0, false, 2>, grid);
+    run("NV4 permuted lanes (16 apart) nt", k_read<4, 0, true, 2>, grid);
+    run("NV4 permuted nt + 64 VALU / vector", k_read<4, 64, true, 2>, grid);
+    run("NV4 contiguous nt + 64 VALU / vector", k_read<4, 64, true, 0>, grid);
+    run("NV4 runs + 64 VALU / vector", k_read<4, 64, false, 1>, grid);
   }
   for (int grid : {4096, 8192}) {
     run("NV4 + 16 VALU / vector", k_read<4, 16, false, false>, grid);
