@@ -127,6 +127,7 @@ class ModelSweep:
         self.launches_hint = sum(-(-sum(1 for i in self.mine if self.layers[i][1] == sh) // 32)
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
+        self.plan = None
         f0, _, g0 = self.passes[0]   # the lists of the first pass feed the model-wide percentile
         self.total_vectors = sum(r if g0 is None else r * c // g0 for _, (r, c) in self.layers)
         self.index = torch.as_tensor([p * self.n_layers + i for p in range(len(self.passes)) for i in self.mine],
@@ -144,17 +145,15 @@ class ModelSweep:
     def step(self):
         import torch
         from quantization_amd.distributed import gather_records, joint_percentile
-        from quantization_amd.report import RECORD_FIELDS, model_records
-        recs, vecs = [], []
-        for k, (fmt, bits, gs) in enumerate(self.passes):
-            if not self.weights:
-                break
-            if k == 0:   # the per-channel lists of the first format feed the model-wide percentile
-                r, vecs = model_records(self.weights, fmt, bits, gs, abs_p99=False, return_vecs=True)
-            else:
-                r = model_records(self.weights, fmt, bits, gs, abs_p99=False)
-            recs.append(r)
-        local = torch.cat(recs) if recs else None
+        from quantization_amd.report import RECORD_FIELDS, SweepPlan
+        local, vecs = None, []
+        if self.weights:
+            # every pass of the sweep over this rank's resident layers (launch descriptors and buffers prepared once);
+            # the per-channel lists of the first pass feed the model-wide percentile
+            if self.plan is None:
+                self.plan = SweepPlan(self.weights, self.passes)
+            local = self.plan.run().reshape(-1, len(RECORD_FIELDS))
+            vecs = self.plan.lists(0)
         # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
         table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
         # ... and the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists

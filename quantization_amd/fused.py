@@ -180,6 +180,27 @@ class _QuantItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("out", _lib.QuantOut)]
 
 
+def bind_batch():
+    """libmq.so with the batch entry points' ctypes signatures set."""
+    L_ = _lib.lib()
+    if not getattr(L_, "_batch_bound", False):
+        L_.mq_quantize_batch_workspace_bytes.restype = ctypes.c_size_t
+        L_.mq_quantize_batch_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                                         ctypes.POINTER(_lib.QuantCfg)]
+        L_.mq_quantize_batch.restype = ctypes.c_int
+        L_.mq_quantize_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.c_void_p]
+        L_.mq_quantize_p99_batch_workspace_bytes.restype = ctypes.c_size_t
+        L_.mq_quantize_p99_batch_workspace_bytes.argtypes = L_.mq_quantize_batch_workspace_bytes.argtypes
+        L_.mq_quantize_p99_batch.restype = ctypes.c_int
+        L_.mq_quantize_p99_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        L_._batch_bound = True
+    return L_
+
+
 @torch.no_grad()
 def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
                    f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, seg_mse=False,
@@ -288,22 +309,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
             o.seg_sse = p_seg + i * s_seg
         if p_tot is not None:
             o.totals = p_tot + i * s_tot
-    L_ = _lib.lib()
-    if not getattr(L_, "_batch_bound", False):
-        L_.mq_quantize_batch_workspace_bytes.restype = ctypes.c_size_t
-        L_.mq_quantize_batch_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
-                                                         ctypes.POINTER(_lib.QuantCfg)]
-        L_.mq_quantize_batch.restype = ctypes.c_int
-        L_.mq_quantize_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
-                                         ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_void_p,
-                                         ctypes.c_size_t, ctypes.c_void_p]
-        L_.mq_quantize_p99_batch_workspace_bytes.restype = ctypes.c_size_t
-        L_.mq_quantize_p99_batch_workspace_bytes.argtypes = L_.mq_quantize_batch_workspace_bytes.argtypes
-        L_.mq_quantize_p99_batch.restype = ctypes.c_int
-        L_.mq_quantize_p99_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
-                                             ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
-                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-        L_._batch_bound = True
+    L_ = bind_batch()
     with torch.cuda.device(dev):
         if p99 is not None:
             ws, stream = workspace(dev, L_.mq_quantize_p99_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))

@@ -115,14 +115,25 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         if return_vecs:
             raise ValueError("return_vecs is not available for the explicit-list tables")
         return torch.stack([layer_record(w, datatype, bits, group_size, abs_p99=abs_p99) for w in weights])
+    state = _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes)
+    out = _finish_pass(weights, state, abs_p99, pct)
+    if return_vecs:
+        vec_rows, keep = state[0], state[1]
+        vecs = [v for r in keep for v in r.seg_mse.unbind(0)]
+        order = {i: k for k, i in enumerate(vec_rows)}
+        return out, [vecs[order[i]] for i in range(len(weights))]
+    return out
+
+
+def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes):
+    """The fused quantize launches of one pass over a model (current stream): layers grouped by (shape, dtype), one
+    launch per 32 of them.  -> (layer index per result row, results, totals, |err| P99s)"""
     groups: Dict[Tuple, List[int]] = {}
     for i, w in enumerate(weights):
         if w.dim() != 2:
             raise ValueError("model_records() takes 2-D weights")
         groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
-    # per-vector MSE lists of ALL layers: one set of select launches at the end; the launches' small results are
-    # gathered with one concatenation and one permutation (no per-launch host <-> device traffic)
-    vec_rows, vecs, keep, tots, p99s = [], [], [], [], []
+    vec_rows, keep, tots, p99s = [], [], [], []
     for (shape, _), idx in groups.items():
         K, C = shape
         per = K * C * 4 if abs_p99 else 1
@@ -140,10 +151,19 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
                 res._bufs.pop("abs_err", None)   # the |err| scratch of this launch is free for the next one
             keep.append(res)
             vec_rows += sel
-            if return_vecs:
-                vecs += list(res.seg_mse.unbind(0))
+    return vec_rows, keep, tots, p99s
+
+
+def _finish_pass(weights, state, abs_p99, pct):
+    """Per-vector P99s of every layer of a pass (one set of select launches) and the record table, on the current
+    stream; the launches' small results are gathered with one concatenation and one permutation (no per-launch
+    host <-> device traffic)."""
+    vec_rows, keep, tots, p99s = state
+    dev = weights[0].device
     p99v = percentile_rows([r.seg_mse for r in keep], pct, wide=True)
-    host = torch.tensor([[float(weights[i].numel()), float(i)] for i in vec_rows], dtype=torch.float64).to(dev)
+    # (pinned + non_blocking: a pageable host-to-device copy would make the host wait for every launch above)
+    host = torch.tensor([[float(weights[i].numel()), float(i)] for i in vec_rows], dtype=torch.float64,
+                        pin_memory=True).to(dev, non_blocking=True)
     numel, tot = host[:, 0], torch.cat(tots)
     mse = tot[:, 0] / numel
     # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
@@ -152,10 +172,136 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     rec = torch.stack([numel, tot[:, 0], tot[:, 1], mse, p99v, a99], dim=1)
     out = torch.empty_like(rec)
     out[host[:, 1].long()] = rec            # launch order -> the order of `weights`
-    if return_vecs:
-        order = {i: k for k, i in enumerate(vec_rows)}
-        return out, [vecs[order[i]] for i in range(len(weights))]
     return out
+
+
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class SweepPlan:
+    """The error-statistics sweep of export_and_quant.sh / quant_error_multi_weight.sh -- every (datatype, bits,
+    group_size) of `passes` over every weight of a model -- prepared once for weights that stay resident: launch
+    descriptors, output buffers and the selection's pointer tables are built here, run() only enqueues.
+
+    run() -> float64 [len(passes), len(weights), len(RECORD_FIELDS)] records (numel, sse, sum_abs, mse_rep, mse_p99,
+    0).  lists(k) -> the float32 per-vector MSE lists of pass k, in the order of `weights`.  Records and lists live in
+    buffers of the plan: the next run() overwrites them.
+
+    Per pass the layers are grouped by (shape, dtype), one fused launch per 32 of them (mq_quantize_batch,
+    statistics only, float32 MSE lists).  The selections of pass k -- chains of short launches that leave most of
+    the chip idle -- run on a second HIP stream while the current stream already streams the weights for pass
+    k + 1; the streams are joined before run() returns, so the result is ordered on the current stream."""
+
+    def __init__(self, weights, passes, pct: float = 99.0):
+        import ctypes
+        from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
+        self.weights = list(weights)
+        self.passes = list(passes)
+        self.pct = float(pct)
+        if not self.weights or not self.passes:
+            raise ValueError("SweepPlan needs at least one weight and one pass")
+        dev = self.dev = self.weights[0].device
+        groups: Dict[Tuple, List[int]] = {}
+        for i, w in enumerate(self.weights):
+            if w.dim() != 2 or not w.is_cuda or w.device != dev or w.dtype not in _DTYPES or not w.is_contiguous():
+                raise ValueError("SweepPlan takes contiguous 2-D float16 / bfloat16 / float32 ROCm weights on one device")
+            groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
+        self.order = [i for idx in groups.values() for i in idx]           # launch order -> index into weights
+        nl = len(self.order)
+        self.L = bind_batch()
+        from . import error_metrics
+        error_metrics._bind()
+        self.numel = torch.tensor([float(self.weights[i].numel()) for i in self.order], dtype=torch.float64, device=dev)
+        self.perm = torch.tensor(self.order, dtype=torch.int64, device=dev)
+        self.records = torch.zeros(len(self.passes), nl, len(RECORD_FIELDS), dtype=torch.float64, device=dev)
+        self.ws_bytes = 0
+        self.plan = []
+        for datatype, bits, group_size in self.passes:
+            fmt, table = format_code(datatype)
+            if table in TABLE_LISTS:
+                raise ValueError("SweepPlan: the explicit-list tables go layer by layer (model_records)")
+            cfg = make_cfg(fmt, bits, group_size, table)
+            totals = torch.zeros(nl, 2, dtype=torch.float64, device=dev)
+            p99 = torch.zeros(nl, dtype=torch.float64, device=dev)
+            launches, lists, ptrs, ns, row = [], [None] * len(self.weights), [], [], 0
+            for (shape, dtype), idx in groups.items():
+                K, C = shape
+                gs = cfg.group_size
+                Lseg = K * C if gs == -1 else (C if gs <= 0 else gs)
+                if gs > 0 and C % gs:
+                    raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {K * C}")
+                nseg = K * C // Lseg
+                nseg_pad = (nseg + 7) // 8 * 8
+                for lo in range(0, len(idx), 32):
+                    sel = idx[lo:lo + 32]
+                    B = len(sel)
+                    mse = torch.empty(B, nseg_pad, dtype=torch.float32, device=dev)
+                    items = (_QuantItem * B)()
+                    for j, i in enumerate(sel):
+                        items[j].w = self.weights[i].data_ptr()
+                        o = items[j].out
+                        o.abs_err_dtype = _lib.F32
+                        o.seg_mse_f32 = 1
+                        o.seg_sse = mse.data_ptr() + j * nseg_pad * 4
+                        o.totals = totals.data_ptr() + (row + j) * 16
+                        lists[i] = mse[j, :nseg]
+                        ptrs.append(o.seg_sse)
+                        ns.append(nseg)
+                    self.ws_bytes = max(self.ws_bytes, self.L.mq_quantize_batch_workspace_bytes(B, K, C, ctypes.byref(cfg)))
+                    launches.append((items, B, _DTYPES[dtype], K, C, mse))
+                    row += B
+            self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists,
+                                  ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns)))
+        self.sel_ws_bytes = self.L.mq_percentile_batch_workspace_bytes(min(nl, 64))
+
+    def lists(self, k: int):
+        return self.plan[k]["lists"]
+
+    @torch.no_grad()
+    def run(self) -> torch.Tensor:
+        import ctypes
+        from .fused import workspace
+        dev, L = self.dev, self.L
+        nl = len(self.order)
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream(dev)
+            side = _side_streams.get(dev.index)
+            if side is None:
+                side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)      # (the previous consumers of the plan's buffers are ordered on `main`)
+            ws, _ = workspace(dev, self.ws_bytes)
+            for k, ps in enumerate(self.plan):
+                cfg = ps["cfg"]
+                for items, B, dt, K, C, _ in ps["launches"]:
+                    _lib.check(L.mq_quantize_batch(items, B, dt, K, C, ctypes.byref(cfg), ws.data_ptr(), ws.numel(),
+                                                   main.cuda_stream))
+                ready = torch.cuda.Event()
+                ready.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    sws, _ = workspace(dev, self.sel_ws_bytes)
+                    _lib.check(L.mq_percentile_multi(ps["ptrs"], ps["ns"], nl, _lib.F32_AS_F64, self.pct,
+                                                     ps["p99"].data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                     side.cuda_stream))
+                    tot = ps["totals"]
+                    mse = tot[:, 0] / self.numel
+                    # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
+                    p99 = torch.where(torch.isnan(mse), mse, ps["p99"])
+                    rec = torch.stack([self.numel, tot[:, 0], tot[:, 1], mse, p99, torch.zeros_like(mse)], dim=1)
+                    self.records[k].index_copy_(0, self.perm, rec)
+            main.wait_stream(side)
+        return self.records
+
+
+@torch.no_grad()
+def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = None):
+    """model_records(weights, datatype, bits, group_size, abs_p99=False) for every (datatype, bits, group_size) of
+    `passes`, one shot: float64 [len(passes), len(weights), len(RECORD_FIELDS)] (and, with vecs_of = k, the
+    per-vector MSE lists of pass k).  Builds a SweepPlan and runs it once; keep the plan to sweep the same
+    resident weights repeatedly."""
+    plan = SweepPlan(weights, passes, pct)
+    out = plan.run()
+    return (out, plan.lists(vecs_of)) if vecs_of is not None else out
 
 
 def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", device=None) -> List[Dict]:

@@ -219,3 +219,21 @@ def test_percentile_rows_equals_numpy():
     assert got32.cpu().numpy().tobytes() == np.percentile(a, 50, axis=1).astype(np.float32).tobytes()
     with pytest.raises(ValueError):
         em.percentile_rows([torch.from_numpy(a).cuda()[:, 1:]], 99)        # rows off the 16-byte grid
+
+
+def test_model_sweep_equals_model_records():
+    """model_sweep (selections of pass k on a second stream under the launches of pass k + 1) returns the records
+    and lists of model_records pass by pass, bit for bit, call after call."""
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(1024, 2048), (256, 2048), (1024, 2048), (2048, 5632), (256, 2048), (4096, 1024)]
+    ws = [(torch.randn(*s, generator=g, device="cuda") * 0.02).bfloat16() for s in shapes]
+    passes = [("int8", 8, None), ("int8", 8, 32), ("int8_asym", 8, 128), ("fp8_e4m3", 8, 64), ("int8", 8, 128)]
+    for _ in range(3):
+        got, vecs = report.model_sweep(ws, passes, vecs_of=1)
+        for k, (dt, bits, gs) in enumerate(passes):
+            want, wv = report.model_records(ws, dt, bits, gs, abs_p99=False, return_vecs=True)
+            assert torch.equal(got[k].view(torch.int64), want.view(torch.int64)), (dt, gs)
+            if k == 1:
+                assert all(torch.equal(a, b) for a, b in zip(vecs, wv))
+    torch.cuda.synchronize()
