@@ -77,7 +77,11 @@ typedef struct {
   int32_t abs_err_dtype; /* MQ_F32: onnx_error_cli.py:90-91;  MQ_F16: single_weight_quant_error.py:39-40 */
   int32_t seg_mse_f32;   /* 0: seg_sse receives float64 sums; 1: seg_sse points to a float32 [nseg] array that
                             receives each segment's mean squared error, float32(sum * (1 / length)): the list
-                            entry compute_mse returns, a float32 np.mean (quant_error_single_weight.py:46-48) */
+                            entry compute_mse returns, a float32 np.mean (quant_error_single_weight.py:46-48),
+                            to 1e-6; 2: the same array, each entry summed in float32 in the order of numpy's
+                            pairwise summation, so that it has the BITS of np.mean(diff * diff) -- statistics-only
+                            calls (no deq / codes / abs_err) on float16 / bfloat16 weights with groups of 32, 64
+                            or 128 elements; anything else returns MQ_ERR_UNSUPPORTED */
   double* seg_sse;       /* float64 [nseg] sum of squared float32 errors per segment (row form,
                             quant_error_single_weight.py:56-71 before the division by the length)  */
   double* totals;        /* float64 [2]: sum of squared errors, sum of absolute errors (float32 errors,

@@ -79,6 +79,7 @@ struct QuantParams {
   double* seg_sse;
   double seg_mse_scale;  // 0: seg_sse receives float64 sums; 1 / L: seg_sse points to float32 words that receive
                          // the segment's mean squared error float32(sum * (1 / L))
+  int32_t seg_exact;     // the float32 entry is summed in numpy's pairwise order instead (k_stats_group<.., true>)
   double* partials;      // [gridDim.x][2]
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
   int32_t sel_mode;      // SEL_FEED_*: feed the float32 |error| values to a percentile selection
@@ -91,6 +92,7 @@ struct Acc {
   double abs;   // sum of |error|
   SelFeed sel;  // selection feed (off unless sel_mode)
   float* xp;    // this wave's 512-float LDS exchange area for the float32 |error| stores, or null
+  float* sq = nullptr;  // per-element path of the statistics kernels: where the 8 float32 squared errors go, or null
 };
 extern __shared__ uint32_t sel_lds[];  // 2 * SEL_FEED_HASH words when sel_mode is on, else none
 
@@ -598,9 +600,11 @@ __device__ __forceinline__ uint32_t lut_round_mag_pk(uint32_t xw, uint32_t vw, c
 // One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements are ADDED to the caller's
 // (the caller carries everything above a few vectors in float64).
 // PK16: the integer formats divide in packed float16 (div_pk16; sp must carry pk_p / pk_s / pk_r: stats_params).
-template <int FMT, bool PK16 = false>
+// SQ: the 8 float32 squared errors (exact: a float16 error squared has 22 significant bits) also go to sq[0..7], in
+// element order, for the list entries summed in numpy's order (numpy_entry).
+template <int FMT, bool PK16 = false, bool SQ = false>
 __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 raw, const SegP& sp, float& sse,
-                                             float& sabs) {
+                                             float& sabs, float* sq = nullptr) {
   const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
   float q = 0.f, q1 = 0.f;
@@ -631,12 +635,18 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
       q = __builtin_fmaf(e0, e0, q);    // two chains of 4 steps per vector, as the dot form has
       q1 = __builtin_fmaf(e1, e1, q1);
       sabs += __builtin_fabsf(e0) + __builtin_fabsf(e1);
+      if constexpr (SQ) { sq[2 * k] = e0 * e0; sq[2 * k + 1] = e1 * e1; }
       continue;
     } else {
       e = as_h2(vw) - as_h2(lut_round_pk_sub(as_u32(x), p.lut)) * s2;
     }
     q = __builtin_amdgcn_fdot2(e, e, q, false);
     sabs = __builtin_amdgcn_fdot2(as_h2(as_u32(e) & 0x7fff7fffu), as_h2(0x3c003c00u), sabs, false);
+    if constexpr (SQ) {
+      const float e0 = (float)e[0], e1 = (float)e[1];
+      sq[2 * k] = e0 * e0;
+      sq[2 * k + 1] = e1 * e1;
+    }
   }
   if constexpr (FMT == MQ_LUT_FP) q += q1;
   sse += q;
@@ -775,6 +785,12 @@ __device__ __forceinline__ double quant8_slow(const QuantParams& p, const u32x4 
     }
     error_sums(e, sse, acc.abs);
     if constexpr (SEL_FEEDS(SEL)) sel_feed8<SEL>(acc.sel, e, e0);
+    if constexpr (SEL == SEL_STATS_ONLY) {
+      if (acc.sq) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.sq[i] = e[i] * e[i];
+      }
+    }
   }
   return sse;
 }
@@ -1249,22 +1265,51 @@ __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p)
   return sp;
 }
 // NV vectors of one segment held by this lane (fast path) -> float64 sum of squared errors, sum of |error|
-template <int FMT, int NV>
+template <int FMT, int NV, bool SQ = false>
 __device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4* raw, const SegP& sp, double& sse,
-                                              double& sabs) {
+                                              double& sabs, float (*sq)[8] = nullptr) {
   // float32 within two vectors (squares: 8 dot steps + 1 add) resp. four vectors (|error|), float64 above
   sse = 0.0;
   sabs = 0.0;
   float q = 0.f, ab = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    quant8_stats<FMT, true>(p, raw[j], sp, q, ab);
+    if constexpr (SQ) quant8_stats<FMT, true, true>(p, raw[j], sp, q, ab, sq[j]);
+    else quant8_stats<FMT, true>(p, raw[j], sp, q, ab);
     if ((j & 1) == 1 || j == NV - 1) { sse += (double)q; q = 0.f; }
     if ((j & 3) == 3 || j == NV - 1) { sabs += (double)ab; ab = 0.f; }
     // one vector's arithmetic at a time: interleaving all NV of them costs 100+ registers of temporaries
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+// The float32 sum of a segment's squared errors in the order numpy's pairwise summation takes for a contiguous
+// run of n <= 128 elements (n a multiple of 8) -- what np.mean(diff * diff) of compute_mse adds up
+// (quant_error_single_weight.py:46-48; numpy/_core/src/umath/loops_utils.h.src, pairwise sum): eight accumulators
+// r[i] = a[i], then r[i] += a[8 k + i] for k = 1, 2, ... in order, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) +
+// (r6 + r7)).  sq: this lane's four vectors of the segment, in memory order; the T lanes of a team hold
+// consecutive quarters of it, so the chain runs through the lanes one after the other: in round q lane q of the
+// team continues from what lane q - 1 handed over (a quad-permute), and after T rounds lane T - 1 holds the
+// accumulators of the whole segment (the other lanes' values are not used).  0 + a = a exactly, so the first
+// lane may start from zeros.  Valid in the team's LAST lane.
+template <int T>
+__device__ __forceinline__ float numpy_entry(const float (*sq)[8]) {
+  static_assert(T == 1 || T == 2 || T == 4, "segments of 32, 64 or 128 elements");
+  float in[8], r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) in[i] = 0.f;
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (((in[i] + sq[0][i]) + sq[1][i]) + sq[2][i]) + sq[3][i];
+    if (q + 1 < T) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)  // lane l takes r of lane l - 1 (quad_perm [0, 0, 1, 2])
+        in[i] = f_from_bits((uint32_t)__builtin_amdgcn_update_dpp(0, (int)f_bits(r[i]), 0x90, 0xf, 0xf, false));
+    }
+  }
+  return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
 // Segments off the fast path (inf / NaN, a clamped scale, asymmetric rows on one side of zero ...) are rare and
 // their per-element code is register-hungry.  The main loops skip them (no stores, nothing added to the sums) and
 // remember that one was seen; a second loop after the main one -- whose registers the prefetch buffers no longer
@@ -1272,18 +1317,31 @@ __device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4*
 // at first.
 template <int FMT>
 __device__ __forceinline__ void stats_slow_segment(const QuantParams& p, const SegP& sp, const char* first, int count,
-                                                   int stride, double& sse, double& sabs) {
+                                                   int stride, double& sse, double& sabs, float (*sq)[8] = nullptr) {
   Acc acc;
   acc.abs = 0.0;
   acc.xp = nullptr;
   sse = 0.0;
 #pragma unroll 1
-  for (int j = 0; j < count; ++j)
+  for (int j = 0; j < count; ++j) {
+    float tmp[8];
+    acc.sq = sq ? tmp : nullptr;
     sse += quant8_slow<FMT, SEL_STATS_ONLY>(p, load8_f16(first + (int64_t)j * stride, p.in_dtype, 0), sp, 0, acc);
+    if (sq) {  // (j is not a compile-time index: spread the copy over the four rows)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (jj == j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sq[jj][i] = tmp[i];
+        }
+    }
+  }
   sabs = acc.abs;
 }
 
-template <int FMT, bool BF16, int T>
+// EXACT: the per-segment output is the float32 mean squared error summed in numpy's order (numpy_entry), written
+// by the team's last lane; T <= 4 (segments of up to 128 elements).
+template <int FMT, bool BF16, int T, bool EXACT = false>
 __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   constexpr int NV = 4, SPW = 64 / T;  // segments per wave and step: 4 KiB of weights
   const QuantParams p = batch_params(b);
@@ -1302,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   // (The table formats are bound by instruction issue, not by the loads: for them the 16 extra instructions cost
   //  more than the better read pattern returns -- fp8_e4m3 g = 128: 117 -> 130 us -- so they keep the direct layout:
   //  lane tl of a team holds vectors tl, tl + T, tl + 2 T, tl + 3 T of its segment, plain loads.)
-  constexpr bool TR = !MQ_IS_LUT(FMT);
+  constexpr bool TR = !MQ_IS_LUT(FMT) || EXACT;  // (numpy's order needs a lane's vectors in memory order)
   const uint32_t loff = TR ? (uint32_t)((4 * (lane & 15) + (lane >> 4)) * 16) : (uint32_t)(team * (64 * T) + tl * 16);
   double acc_sse = 0.0, acc_abs = 0.0;
   bool seen_slow = false;
@@ -1336,13 +1394,19 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
       r[0][k] = e[0]; r[1][k] = e[1]; r[2][k] = f[0]; r[3][k] = f[1];
     }
   };
-  auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take) __attribute__((always_inline)) {
+  auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take, const float (*sq)[8]) __attribute__((always_inline)) {
     const int64_t seg = t * SPW + team;
     const bool valid = (t < full || seg < p.nseg) && take;
     s = take ? s : 0.0;
     acc_sse += s;
     acc_abs += take ? ab : 0.0;
-    if (p.seg_sse) {
+    if constexpr (EXACT) {
+      if constexpr (T <= 4) {
+        // np.mean: the pairwise float32 sum divided by the count, a power of two here (exact)
+        const float entry = numpy_entry<(T <= 4 ? T : 1)>(sq) * (float)p.seg_mse_scale;
+        if (valid && tl == T - 1) reinterpret_cast<float*>(p.seg_sse)[seg] = entry;
+      }
+    } else if (p.seg_sse) {
       s = team_sum<T>(s);
       if (valid && tl == 0) store_seg(p, seg, s);
     }
@@ -1361,8 +1425,14 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
     seen_slow = seen_slow || sp.slow;
     double s, ab;
-    stats_vectors<FMT, NV>(p, raw, sp, s, ab);  // (a lane past the end holds zeros: no error)
-    finish(t, sp, s, ab, !sp.slow);
+    if constexpr (EXACT) {
+      float sq[NV][8];
+      stats_vectors<FMT, NV, true>(p, raw, sp, s, ab, sq);
+      finish(t, sp, s, ab, !sp.slow, sq);
+    } else {
+      stats_vectors<FMT, NV>(p, raw, sp, s, ab);  // (a lane past the end holds zeros: no error)
+      finish(t, sp, s, ab, !sp.slow, nullptr);
+    }
   };
   // two register buffers take turns, so that the next step's loads are in flight while this one is computed and
   // no vector is copied between registers (past the wave's last step the prefetch loads nothing, see stats_bload)
@@ -1391,10 +1461,18 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
       const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
       if (__builtin_amdgcn_ballot_w64(sp.slow) == 0) continue;
       double s = 0.0, ab = 0.0;
+      float sq[NV][8];
+      if constexpr (EXACT) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sq[j][i] = 0.f;
+      }
       if (sp.slow)
         stats_slow_segment<FMT>(p, sp, wb + t * 4096 + (TR ? lane * 64 : (int)loff),
-                                (t < full || t * SPW + team < p.nseg) ? NV : 0, TR ? 16 : 16 * T, s, ab);
-      finish(t, sp, s, ab, sp.slow);
+                                (t < full || t * SPW + team < p.nseg) ? NV : 0, TR ? 16 : 16 * T, s, ab,
+                                EXACT ? sq : nullptr);
+      finish(t, sp, s, ab, sp.slow, sq);
     }
   }
   block_partials(p, acc_sse, acc_abs, lds);
@@ -1876,7 +1954,13 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
 template <int FMT, bool BF16>
 static void launch_stats(int scope, int nv, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
 #define MQ_STATS_ROW(NV, WPR) hipLaunchKernelGGL((k_stats_row<FMT, BF16, NV, WPR>), grid, dim3(256), 0, st, p)
-  if (scope == SC_STATS_GROUP) {
+  if (scope == SC_STATS_GROUP && p.common.seg_exact) {  // (the host admits team_log2 <= 2 only)
+    switch (team_log2) {
+      case 0: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 1, true>), grid, dim3(256), 0, st, p); break;
+      case 1: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 2, true>), grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 4, true>), grid, dim3(256), 0, st, p); break;
+    }
+  } else if (scope == SC_STATS_GROUP) {
     switch (team_log2) {
       case 0: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 1>), grid, dim3(256), 0, st, p); break;
       case 1: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 2>), grid, dim3(256), 0, st, p); break;
@@ -2121,8 +2205,9 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   if (o0.abs_err && o0.abs_err_dtype != MQ_F32 && o0.abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
   p.abs_err_f16 = o0.abs_err_dtype == MQ_F16;
   p.need_err = (o0.abs_err || o0.seg_sse || o0.totals) ? 1 : 0;
-  if (o0.seg_mse_f32 != 0 && o0.seg_mse_f32 != 1) return MQ_ERR_ARG;
+  if (o0.seg_mse_f32 < 0 || o0.seg_mse_f32 > 2) return MQ_ERR_ARG;
   p.seg_mse_scale = (o0.seg_sse && o0.seg_mse_f32) ? 1.0 / (double)p.L : 0.0;
+  p.seg_exact = (o0.seg_sse && o0.seg_mse_f32 == 2) ? 1 : 0;
   p.tred = static_cast<const uint32_t*>(workspace);
   b.ws_stride = (int64_t)ws_slice_bytes();
   const size_t esz = w_dtype == MQ_F32 ? 4 : 2;
@@ -2240,9 +2325,12 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
     team_log2 = ilog2_ceil(p.L / 32);
     nv = -4;
     if (stats_kernels) scope = SC_STATS_GROUP;
+    if (p.seg_exact && !(stats_kernels && team_log2 <= 2)) return MQ_ERR_UNSUPPORTED;
     const int64_t spw = 64 >> team_log2;
     const int64_t wb = ((p.nseg + spw - 1) / spw + 3) / 4;
     grid.x = (unsigned)(wb < max_grid ? wb : max_grid);
+  } else if (p.seg_exact) {
+    return MQ_ERR_UNSUPPORTED;  // numpy-order entries: statistics-only groups of 32 / 64 / 128 elements
   } else if (stats_kernels && (scope == SC_WAVE || scope == SC_BLOCK) && p.L / 8 <= 4096) {
     const int64_t vecs = p.L / 8;
     int64_t wb;

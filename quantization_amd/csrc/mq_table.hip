@@ -350,6 +350,7 @@ extern "C" int mq_quantize_table(const void* w, int32_t w_dtype, int64_t rows, i
   if (n == 0) return MQ_OK;
   if (!w) return MQ_ERR_ARG;
   if (out->abs_err && out->abs_err_dtype != MQ_F32 && out->abs_err_dtype != MQ_F16) return MQ_ERR_ARG;
+  if (out->seg_mse_f32 == 2) return MQ_ERR_UNSUPPORTED;  // numpy-order entries: mq_quantize's group kernels only
   if (out->seg_mse_f32 != 0 && out->seg_mse_f32 != 1) return MQ_ERR_ARG;
   if (!workspace || workspace_bytes < mq_quantize_table_workspace_bytes(rows, cols, cfg)) return MQ_ERR_WORKSPACE;
   const size_t wide = cfg->math == MQ_TABLE_F16 ? 2 : 4;  // element size of codes / scale

@@ -111,6 +111,15 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _seg_flag(seg_mse):
+    """mq_quant_out.seg_mse_f32: 0 float64 sums, 1 float32 MSEs, 2 float32 MSEs with numpy's summation order."""
+    if seg_mse == "numpy":
+        return 2
+    if seg_mse in (True, False, None, 0, 1):
+        return int(bool(seg_mse))
+    raise ValueError("seg_mse: False, True or 'numpy'")
+
+
 @torch.no_grad()
 def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype: Optional[str] = None, *,
              f32_math=False, deq=True, codes=True, scale=True, abs_err=None, seg_sse=False, seg_mse=False,
@@ -119,7 +128,9 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
 
     abs_err: None, torch.float32 or torch.float16.  seg_sse: float64 sums of squared errors per segment; seg_mse:
     the float32 mean squared error per segment instead (the per-vector MSE list of
-    quant_error_single_weight.py:56-71, whose entries are float32 means) -- one of the two.  `out` may carry
+    quant_error_single_weight.py:56-71, whose entries are float32 means) -- one of the two.  seg_mse="numpy": the
+    entries are summed in numpy's pairwise order and equal np.mean(diff * diff) bit for bit (statistics-only calls
+    with groups of 32 / 64 / 128 elements; ValueError otherwise).  `out` may carry
     preallocated tensors to reuse.
     """
     if seg_sse and seg_mse:
@@ -166,7 +177,7 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
     o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale),
                       zero_point=_ptr(res.zero_point), abs_err=_ptr(res.abs_err),
                       abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
-                      seg_mse_f32=int(bool(seg_mse)), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
+                      seg_mse_f32=_seg_flag(seg_mse), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
                       totals=_ptr(res.totals))
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L_.mq_quantize_workspace_bytes(rows, cols, ctypes.byref(cfg)))
@@ -286,7 +297,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
 
     items = (_QuantItem * B)()
     aed = _lib.F16 if abs_err == torch.float16 else _lib.F32
-    seg_flag = int(bool(seg_mse))
+    seg_flag = _seg_flag(seg_mse)
     (p_deq, s_deq), (p_codes, s_codes), (p_scale, s_scale), (p_zp, s_zp) = span(b_deq), span(b_codes), span(b_scale), span(b_zp)
     (p_abs, s_abs), (p_seg, s_seg), (p_tot, s_tot) = span(b_abs), span(b_mse if seg_mse else b_sse), span(b_tot)
     for i in range(B):
@@ -377,7 +388,7 @@ def quantize_table(w: torch.Tensor, values, math: int, group_size=None, *, deq_d
     L_ = _lib.lib()
     o = _lib.QuantOut(deq=_ptr(res.deq), codes=_ptr(res.codes), scale=_ptr(res.scale), zero_point=None,
                       abs_err=_ptr(res.abs_err), abs_err_dtype=_lib.F16 if abs_err == torch.float16 else _lib.F32,
-                      seg_mse_f32=int(bool(seg_mse)), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
+                      seg_mse_f32=_seg_flag(seg_mse), seg_sse=_ptr(res.seg_mse if seg_mse else res.seg_sse),
                       totals=_ptr(res.totals))
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L_.mq_quantize_table_workspace_bytes(rows, cols, ctypes.byref(cfg)))

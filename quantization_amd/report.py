@@ -88,7 +88,7 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
 
 @torch.no_grad()
 def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool = True, pct: float = 99.0,
-                  max_err_bytes: int = 8 << 30, return_vecs: bool = False):
+                  max_err_bytes: int = 8 << 30, return_vecs: bool = False, numpy_order: bool = False):
     """layer_record(form="single") for every weight of a model at once: float64 [len(weights), len(RECORD_FIELDS)]
     on the device, nothing synchronised.
 
@@ -105,7 +105,11 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     float32 bits and interpolated in float64 like np.percentile of the float64 array of those values (:79).
     mse_rep (:78, the mean of the list) is the tensor's squared-error sum over its element count: every vector of
     a weight has the same length, so the two are the same number up to the float32 rounding of the list entries
-    (6e-8 relative), and no pass over the list is needed for it."""
+    (6e-8 relative), and no pass over the list is needed for it.
+
+    numpy_order (groups of 32 / 64 / 128 elements, abs_p99=False): the list entries are summed in numpy's pairwise
+    order and have the bits of the scripts' entries, so mse_p99 equals the reference's float(np.percentile(vec, 99))
+    bit for bit (the kernels spend ~T more float32 additions per element pair for it; mse_rep stays as above)."""
     fmt, table = format_code(datatype)
     weights = list(weights)
     if not weights:
@@ -115,7 +119,9 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         if return_vecs:
             raise ValueError("return_vecs is not available for the explicit-list tables")
         return torch.stack([layer_record(w, datatype, bits, group_size, abs_p99=abs_p99) for w in weights])
-    state = _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes)
+    if numpy_order and abs_p99:
+        raise ValueError("numpy_order is a statistics-only mode: pass abs_p99=False")
+    state = _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes, numpy_order)
     out = _finish_pass(weights, state, abs_p99, pct)
     if return_vecs:
         vec_rows, keep = state[0], state[1]
@@ -125,7 +131,7 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     return out
 
 
-def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes):
+def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes, numpy_order=False):
     """The fused quantize launches of one pass over a model (current stream): layers grouped by (shape, dtype), one
     launch per 32 of them.  -> (layer index per result row, results, totals, |err| P99s)"""
     groups: Dict[Tuple, List[int]] = {}
@@ -142,7 +148,8 @@ def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_by
             sel = idx[lo:lo + chunk]
             # (every chunk keeps its own result: the lists are read by the selection after the last launch)
             res = quantize_batch([weights[i] for i in sel], fmt, bits, group_size, table, deq=False, codes=False,
-                                 scale=False, abs_err=torch.float32 if abs_p99 else None, seg_mse=True, totals=True,
+                                 scale=False, abs_err=torch.float32 if abs_p99 else None,
+                                 seg_mse="numpy" if numpy_order else True, totals=True,
                                  p99=pct if abs_p99 else None)
             tots.append(res.totals)
             if abs_p99:
@@ -190,9 +197,10 @@ class SweepPlan:
     Per pass the layers are grouped by (shape, dtype), one fused launch per 32 of them (mq_quantize_batch,
     statistics only, float32 MSE lists).  The selections of pass k -- chains of short launches that leave most of
     the chip idle -- run on a second HIP stream while the current stream already streams the weights for pass
-    k + 1; the streams are joined before run() returns, so the result is ordered on the current stream."""
+    k + 1; the streams are joined before run() returns, so the result is ordered on the current stream.
+    numpy_order: as for model_records (every pass must then be per-group with 32 / 64 / 128 elements)."""
 
-    def __init__(self, weights, passes, pct: float = 99.0):
+    def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False):
         import ctypes
         from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
         self.weights = list(weights)
@@ -241,7 +249,7 @@ class SweepPlan:
                         items[j].w = self.weights[i].data_ptr()
                         o = items[j].out
                         o.abs_err_dtype = _lib.F32
-                        o.seg_mse_f32 = 1
+                        o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
                         o.seg_sse = mse.data_ptr() + j * nseg_pad * 4
                         o.totals = totals.data_ptr() + (row + j) * 16
                         lists[i] = mse[j, :nseg]
