@@ -239,7 +239,7 @@ __device__ __forceinline__ u32x4 bf16x8_to_f16(u32x4 b) {
 // 16-byte load that can stay in flight; float32: converted at once, it needs two loads anyway), raw_to_f16
 // converts bfloat16 when the values are consumed.
 __device__ __forceinline__ u32x4 load8_raw(const void* w, int dtype, int64_t e) {
-  if (dtype != MQ_F32) return *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e);
+  if (dtype != MQ_F32) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + e));
   u32x4 out;
   const f32x4* p = reinterpret_cast<const f32x4*>(static_cast<const float*>(w) + e);
   f32x4 a = p[0], c = p[1];
@@ -493,8 +493,8 @@ __device__ __forceinline__ void store_abs_err(const QuantParams& p, const float*
       f32x4 b0 = x4[lane], b1 = x4[64 + lane];  // moving the reads of other lanes' values above the writes
       __builtin_amdgcn_wave_barrier();
       f32x4* ob = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + (e0 - (int64_t)lane * 8));
-      ob[lane] = b0;
-      ob[64 + lane] = b1;
+      __builtin_nontemporal_store(b0, &ob[lane]);
+      __builtin_nontemporal_store(b1, &ob[64 + lane]);
     } else {
       f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
       o[0] = a0;
@@ -700,10 +700,10 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
     e[2 * k + 1] = v1 - (float)d[1];
   }
   if constexpr (SEL_STORES(SEL)) {
-    if (p.deq) *reinterpret_cast<u32x4*>(p.deq + e0) = dq;
+    if (p.deq) __builtin_nontemporal_store(dq, reinterpret_cast<u32x4*>(p.deq + e0));
     if (p.codes) {
       if constexpr (MQ_IS_LUT(FMT)) {
-        *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0) = cw;
+        __builtin_nontemporal_store(cw, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.codes) + e0));
       } else {
         if constexpr (FMT == MQ_INT_ASYM) {
           // integers 0..255 as float16: the low byte of the bits of 1024 + q is q
@@ -712,7 +712,7 @@ __device__ __forceinline__ double quant8_fast(const QuantParams& p, const u32x4 
           for (int k = 0; k < 4; ++k) cw[k] = as_u32(as_h2(cw[k]) + k1024);
         }
         u32x2 c = {__builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u), __builtin_amdgcn_perm(cw[3], cw[2], 0x06040200u)};
-        *reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0) = c;
+        __builtin_nontemporal_store(c, reinterpret_cast<u32x2*>(static_cast<uint8_t*>(p.codes) + e0));
       }
     }
   }
