@@ -128,6 +128,7 @@ class ModelSweep:
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
         self.plan = None
+        self.overlap = True   # selections of pass k on a second stream under the launches of pass k + 1
         f0, _, g0 = self.passes[0]   # the lists of the first pass feed the model-wide percentile
         self.total_vectors = sum(r if g0 is None else r * c // g0 for _, (r, c) in self.layers)
         self.index = torch.as_tensor([p * self.n_layers + i for p in range(len(self.passes)) for i in self.mine],
@@ -152,7 +153,7 @@ class ModelSweep:
             # the per-channel lists of the first pass feed the model-wide percentile
             if self.plan is None:
                 self.plan = SweepPlan(self.weights, self.passes)
-            local = self.plan.run().reshape(-1, len(RECORD_FIELDS))
+            local = self.plan.run(overlap=self.overlap).reshape(-1, len(RECORD_FIELDS))
             vecs = self.plan.lists(0)
         # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
         table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
@@ -413,6 +414,14 @@ def main():
         wl = Workload(args.workload, device, rank, args.dist)
         total_weight_bytes, local_algo, reserve = wl.weight_bytes, wl.algo_bytes, wl.launches
     wall, gpu_ms, kern_ms, kern_launches = timed_run(wl.step, args.steps, args.warmup, device, dist, world, reserve)
+    isolated = None
+    if sharded:
+        # the same launches with nothing else on the chip (outside the timed region): in the timed steps the
+        # selections of the previous pass share the HBM with them, which lengthens each launch
+        wl.overlap = False
+        _, _, k_iso, n_iso = timed_run(wl.step, 2, 1, device, dist, world, reserve)
+        wl.overlap = True
+        isolated = (k_iso, n_iso)
 
     # per-rank shares, for the record
     shares = None
@@ -447,6 +456,12 @@ def main():
             "roofline": roofline(local_algo, args.steps, kern_ms, kern_launches, wl.kernel_desc + " (rank 0)",
                                  traffic_for(args.workload)),
         }
+        if sharded and isolated and isolated[1]:
+            iso = roofline(local_algo, 2, isolated[0], isolated[1], "", None)
+            out["roofline"]["launch_alone"] = {
+                "avg_launch_us": iso["avg_launch_us"], "achieved": iso["achieved"], "frac": iso["frac"],
+                "note": "the same launches in 2 extra untimed steps with the selections kept on the same stream: in the "
+                        "timed steps the previous pass's selections run concurrently on a second stream and share the HBM"}
         if sharded:
             out["config"].update({
                 "backend": backend if world > 1 else "none (one rank)",

@@ -266,14 +266,16 @@ class SweepPlan:
         return self.plan[k]["lists"]
 
     @torch.no_grad()
-    def run(self) -> torch.Tensor:
+    def run(self, overlap: bool = True) -> torch.Tensor:
+        """overlap=False keeps everything on the current stream (the selections of a pass then run between the
+        passes, alone on the chip): for measurements of the quantize launches by themselves."""
         import ctypes
         from .fused import workspace
         dev, L = self.dev, self.L
         nl = len(self.order)
         with torch.cuda.device(dev):
             main = torch.cuda.current_stream(dev)
-            side = _side_streams.get(dev.index)
+            side = _side_streams.get(dev.index) if overlap else main
             if side is None:
                 side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)      # (the previous consumers of the plan's buffers are ordered on `main`)
