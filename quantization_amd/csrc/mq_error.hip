@@ -21,6 +21,7 @@ struct ErrParams {
   double* seg_sse;
   double* col_part;  // [row_chunks][cols] partial column sums, or null
   int32_t row_chunks;
+  int32_t cols_totals;  // k_err_cols also leaves the workgroup's sum of squares / |error| in partials[]
   double* partials;  // [grid][2]
 };
 
@@ -28,11 +29,11 @@ struct ErrParams {
 __device__ __forceinline__ void load8(const void* p, int dtype, int64_t e, float* x) {
   if (dtype == MQ_F32) {
     const f32x4* q = reinterpret_cast<const f32x4*>(static_cast<const float*>(p) + e);
-    f32x4 u = q[0], v = q[1];
+    f32x4 u = __builtin_nontemporal_load(&q[0]), v = __builtin_nontemporal_load(&q[1]);  // (touched once)
 #pragma unroll
     for (int k = 0; k < 4; ++k) { x[k] = u[k]; x[4 + k] = v[k]; }
   } else {
-    u32x4 r = *reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(p) + e);
+    u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(p) + e));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       x[2 * k] = (float)h_from_bits(r[k] & 0xffffu);
@@ -57,13 +58,13 @@ __device__ __forceinline__ void err8(const ErrParams& p, int64_t e0, float& psq,
   if (p.abs_err_mode == 1) {
     f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(p.abs_err) + e0);
     f32x4 o0 = {ab[0], ab[1], ab[2], ab[3]}, o1 = {ab[4], ab[5], ab[6], ab[7]};
-    o[0] = o0;
-    o[1] = o1;
+    __builtin_nontemporal_store(o0, &o[0]);
+    __builtin_nontemporal_store(o1, &o[1]);
   } else if (p.abs_err_mode == 2) {
     u32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (f2h_bits(e[2 * k]) | (f2h_bits(e[2 * k + 1]) << 16)) & 0x7fff7fffu;
-    *reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0) = o;
+    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(static_cast<uint16_t*>(p.abs_err) + e0));
   }
   psq = tree8(q);
   pab = tree8(ab);
@@ -137,26 +138,68 @@ __global__ __launch_bounds__(256) void k_err_rows(ErrParams p) {
   err_block_partials(p, acc_sq, acc_ab);
 }
 
-// Column form: thread (cv, rc) owns 8 columns and every row_chunks-th row; partial column sums go to
-// col_part[rc][col] and are added up in a fixed order by k_err_cols_finish.
+// Column form: a workgroup owns 64 column vectors (512 columns) of one row chunk rc; its four waves take every
+// fourth row of the chunk's rows (rows rc, rc + row_chunks, ...), four rows in flight per lane -- the loop is bound
+// by load latency, so the chip wants many waves with several loads each -- and their partial sums meet in LDS in a
+// fixed order.  Partial column sums go to col_part[rc][col] and are added up in a fixed order by k_err_cols_finish.
 __global__ __launch_bounds__(256) void k_err_cols(ErrParams p) {
-  const int64_t cvecs = p.cols / 8;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cvecs * p.row_chunks) return;
-  const int64_t cv = t % cvecs, rc = t / cvecs;
+  __shared__ double part[3][64][8];
+  const int64_t cvecs = p.cols / 8, cblocks = (cvecs + 63) / 64;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t cv = (int64_t)(blockIdx.x % cblocks) * 64 + lane, rc = blockIdx.x / cblocks;
+  const bool in = cv < cvecs;
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t r = rc; r < p.rows; r += p.row_chunks) {
-    float x[8], y[8];
-    load8(p.a, p.dtype, r * p.cols + cv * 8, x);
-    load8(p.b, p.dtype, r * p.cols + cv * 8, y);
+  double sab = 0.0;  // (cols_totals: this lane's sum of |error|, so that one pass over a and b serves both forms)
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)p.row_chunks * 4;  // rows between two rows of one wave
+  int64_t r = rc + (int64_t)wv * p.row_chunks;
+  if (in) {
+    for (; r + (U - 1) * stride < p.rows; r += U * stride) {
+      float x[U][8], y[U][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float e = x[i] - y[i];
-      acc[i] += (double)(e * e);
+      for (int u = 0; u < U; ++u) {
+        load8(p.a, p.dtype, (r + u * stride) * p.cols + cv * 8, x[u]);
+        load8(p.b, p.dtype, (r + u * stride) * p.cols + cv * 8, y[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float ab[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float e = x[u][i] - y[u][i];
+          acc[i] += (double)(e * e);
+          ab[i] = __builtin_fabsf(e);
+        }
+        if (p.cols_totals) sab += (double)tree8(ab);
+      }
+    }
+    for (; r < p.rows; r += stride) {
+      float x[8], y[8], ab[8];
+      load8(p.a, p.dtype, r * p.cols + cv * 8, x);
+      load8(p.b, p.dtype, r * p.cols + cv * 8, y);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float e = x[i] - y[i];
+        acc[i] += (double)(e * e);
+        ab[i] = __builtin_fabsf(e);
+      }
+      if (p.cols_totals) sab += (double)tree8(ab);
     }
   }
+  if (p.cols_totals) {  // (uniform; every thread of the workgroup takes part)
+    const double ssq = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    err_block_partials(p, ssq, sab);
+  }
+  if (wv > 0) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) p.col_part[rc * p.cols + cv * 8 + i] = acc[i];
+    for (int i = 0; i < 8; ++i) part[wv - 1][lane][i] = acc[i];
+  }
+  __syncthreads();
+  if (wv == 0 && in) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      p.col_part[rc * p.cols + cv * 8 + i] = ((acc[i] + part[0][lane][i]) + part[1][lane][i]) + part[2][lane][i];
+  }
 }
 // The same for any column count / alignment: thread (c, rc) owns one column (consecutive lanes read consecutive
 // elements of a row).
@@ -171,14 +214,26 @@ __global__ __launch_bounds__(256) void k_err_cols_scalar(ErrParams p) {
   }
   p.col_part[rc * p.cols + c] = acc;
 }
-// col_sse[c] = sum over chunks; block_sse[g] = sum over the block's columns (column-block form)
+// col_sse[c] = sum over the row chunks, in a fixed order: a workgroup owns 64 columns, wave w adds chunks w, w + 4,
+// ... (four loads in flight), the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void k_err_cols_finish(const double* part, int row_chunks, int64_t cols,
                                                          double* col_sse) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ double ex[3][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int r = 0; r < row_chunks; ++r) s += part[(int64_t)r * cols + c];
-  col_sse[c] = s;
+  if (c < cols) {
+    int r = wv;
+    for (; r + 12 < row_chunks; r += 16) {
+      const double a0 = part[(int64_t)r * cols + c], a1 = part[(int64_t)(r + 4) * cols + c];
+      const double a2 = part[(int64_t)(r + 8) * cols + c], a3 = part[(int64_t)(r + 12) * cols + c];
+      s = (((s + a0) + a1) + a2) + a3;
+    }
+    for (; r < row_chunks; r += 4) s += part[(int64_t)r * cols + c];
+  }
+  if (wv > 0) ex[wv - 1][lane] = s;
+  __syncthreads();
+  if (wv == 0 && c < cols) col_sse[c] = ((s + ex[0][lane]) + ex[1][lane]) + ex[2][lane];
 }
 
 // scalar fallback for shapes that are not whole, aligned 8-element vectors: totals and row segments
@@ -314,12 +369,12 @@ __global__ __launch_bounds__(256) void k_compare_vec(CompareParams p) {
   const uint32_t thr = p.thr_bits & 0xffffu;
   const bool thr_nan = (thr & 0x7fffu) > 0x7c00u, thr_neg = (thr & 0x8000u) != 0;
   for (int64_t v = t0; v < nvec; v += step) {
-    const u32x4 w = reinterpret_cast<const u32x4*>(p.w)[v];
+    const u32x4 w = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(p.w)[v]);  // every byte is touched once
     // (plain arrays: with ext_vector variables as the asm operands hipcc 7.2 used word 0 for every k)
     uint32_t e[NF][4], mn[4], mx[4], mo[4];
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const u32x4 q = reinterpret_cast<const u32x4*>(p.q[f])[v];
+      const u32x4 q = __builtin_nontemporal_load(&reinterpret_cast<const u32x4*>(p.q[f])[v]);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         h16x2 d = __builtin_bit_cast(h16x2, (uint32_t)w[k]) - __builtin_bit_cast(h16x2, (uint32_t)q[k]);
@@ -353,8 +408,8 @@ __global__ __launch_bounds__(256) void k_compare_vec(CompareParams p) {
       fl[i >> 2] |= f8 << ((i & 3) * 8);
       if (i & 1) mo[k] |= m << 16; else mo[k] = m;
     }
-    reinterpret_cast<u32x2*>(p.flags)[v] = u32x2{fl[0], fl[1]};
-    if (p.min_err) reinterpret_cast<u32x4*>(p.min_err)[v] = u32x4{mo[0], mo[1], mo[2], mo[3]};
+    __builtin_nontemporal_store(u32x2{fl[0], fl[1]}, &reinterpret_cast<u32x2*>(p.flags)[v]);
+    if (p.min_err) __builtin_nontemporal_store(u32x4{mo[0], mo[1], mo[2], mo[3]}, &reinterpret_cast<u32x4*>(p.min_err)[v]);
   }
 }
 
@@ -401,8 +456,15 @@ static int error_stats_impl(const void* a, const void* b, int32_t dtype, int64_t
   p.partials = static_cast<double*>(workspace);
   const int64_t L = p.seg_len ? p.seg_len : n;
   const bool vec_ok = L % 8 == 0 && n % 8 == 0 && al(a, 16) && al(b, 16) && al(abs_err, 16);
-  unsigned grid;
-  if (vec_ok) {
+  unsigned grid = 0;
+  // column sums over whole, aligned 8-element vectors: one pass gives them AND the totals (the default form of
+  // quant_error_multi_weight.py: tensor MSE + per-column list)
+  const bool cols_vec = col_sse && cols % 8 == 0 && al(a, 16) && al(b, 16);
+  const bool fused_cols = cols_vec && !seg_sse && !abs_err;
+  const bool need_main = (totals || seg_sse || abs_err) && !fused_cols;
+  if (!need_main) {
+    // nothing for the row pass to do
+  } else if (vec_ok) {
     int64_t waves;
     if (!p.seg_sse) {
       waves = (n / 8 + 63) / 64;
@@ -424,18 +486,31 @@ static int error_stats_impl(const void* a, const void* b, int32_t dtype, int64_t
     hipLaunchKernelGGL(k_err_generic, dim3(grid), dim3(256), 0, st, p);
   }
   MQ_HIP(hipGetLastError());
-  if (totals) hipLaunchKernelGGL(k_err_finalize, dim3(1), dim3(256), 0, st, p.partials, (int)grid, totals);
+  if (totals && need_main) hipLaunchKernelGGL(k_err_finalize, dim3(1), dim3(256), 0, st, p.partials, (int)grid, totals);
   if (col_sse) {
     p.col_part = static_cast<double*>(workspace) + (size_t)kErrMaxGrid * 2;
-    if (cols % 8 == 0 && al(a, 16) && al(b, 16)) {
+    if (cols_vec) {
       // enough (column-vector, row-chunk) threads to fill the chip, at most 64 chunks
       int64_t cvecs = cols / 8;
       int64_t chunks = (256 * 8 * 256 + cvecs - 1) / cvecs;
       chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
       if (chunks > rows) chunks = rows;
       p.row_chunks = (int32_t)chunks;
-      int64_t threads = cvecs * chunks;
-      hipLaunchKernelGGL(k_err_cols, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
+      const unsigned cgrid = (unsigned)(((cvecs + 63) / 64) * chunks);
+      p.cols_totals = (fused_cols && totals && cgrid <= (unsigned)kErrMaxGrid) ? 1 : 0;
+      hipLaunchKernelGGL(k_err_cols, dim3(cgrid), dim3(256), 0, st, p);
+      if (fused_cols && totals) {
+        if (p.cols_totals) {
+          hipLaunchKernelGGL(k_err_finalize, dim3(1), dim3(256), 0, st, p.partials, (int)cgrid, totals);
+        } else {  // (more workgroups than partial slots: the row pass after all)
+          ErrParams q = p;
+          q.col_part = nullptr;
+          const int64_t blocks = ((n / 8 + 63) / 64 + 3) / 4;
+          const unsigned g2 = (unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks));
+          hipLaunchKernelGGL(k_err_rows, dim3(g2), dim3(256), 0, st, q);
+          hipLaunchKernelGGL(k_err_finalize, dim3(1), dim3(256), 0, st, q.partials, (int)g2, totals);
+        }
+      }
     } else {  // any column count or alignment: one column per thread
       int64_t chunks = (256 * 8 * 256 + cols - 1) / cols;
       chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
@@ -444,7 +519,7 @@ static int error_stats_impl(const void* a, const void* b, int32_t dtype, int64_t
       int64_t threads = cols * chunks;
       hipLaunchKernelGGL(k_err_cols_scalar, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, p);
     }
-    hipLaunchKernelGGL(k_err_cols_finish, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, p.col_part,
+    hipLaunchKernelGGL(k_err_cols_finish, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, p.col_part,
                        (int)p.row_chunks, cols, col_sse);
   }
   MQ_HIP(hipGetLastError());
