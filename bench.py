@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the c2 and llama70b_shard results")
+    ap.add_argument("--watchdog", type=int, default=0, metavar="SECONDS",
+                    help="every rank: after SECONDS print all Python stacks to stderr and exit (a hang names itself)")
     return ap.parse_args()
 
 
@@ -349,6 +351,7 @@ def timed_run(step, steps, warmup, device, dist, world, reserve):
     wall = time.perf_counter() - t0
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
+        torch.cuda.synchronize()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     kern_total_ms, kern_launches = ctypes.c_double(0), ctypes.c_int64(0)
     _lib.check(L.mq_profile_end(ctypes.byref(kern_total_ms), ctypes.byref(kern_launches)))
@@ -378,6 +381,9 @@ def main():
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(world_env or "1")
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
@@ -429,6 +435,7 @@ def main():
         mine = torch.tensor([wl.local_weight_bytes, len(wl.mine)], dtype=torch.int64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         if world > 1:
+            torch.cuda.synchronize()
             dist.all_gather(allr, mine)
         else:
             allr = [mine]

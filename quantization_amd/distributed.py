@@ -24,6 +24,15 @@ def lpt_partition(sizes: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(p) for p in parts]
 
 
+def _drain_for_host_backend(group=None) -> None:
+    """gloo (the CPU stand-in for RCCL in rehearsals and tests) stages device tensors through pinned host memory
+    on a worker thread; on ROCm that has been seen to wait forever when the device still has queued work, so the
+    calling stream is drained first.  RCCL collectives are enqueued on the stream and need nothing."""
+    import torch.distributed as dist
+    if dist.get_backend(group) != "nccl" and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tensor], n_total: int, width: int,
                    device, group=None) -> torch.Tensor:
     """Every rank contributes the rows it owns; all ranks get the full [n_total, width] float64 table.
@@ -34,6 +43,7 @@ def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tenso
         idx = local_idx if isinstance(local_idx, torch.Tensor) else torch.as_tensor(list(local_idx), device=device)
         table[idx.to(device)] = local_records.to(torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        _drain_for_host_backend(group)
         dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
     return table
 
@@ -111,6 +121,7 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     if total is None:
         n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
         if dist_on:
+            _drain_for_host_backend(group)
             dist.all_reduce(n, group=group)
         n = int(n.item())
     else:
@@ -133,6 +144,7 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
             L.mq_select_layout(level, ctypes.byref(off), ctypes.byref(cnt))
             # (bin counts stay far below 2^31 for anything that fits a node)
             hist = ws[off.value: off.value + 4 * cnt.value].view(torch.int32)
+            _drain_for_host_backend(group)
             dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
         _lib.check(L.mq_select_scan(level, k0.value, k1.value, int(level == levels), code, gamma.value,
                                     out.data_ptr(), None, wp, wn, st))

@@ -149,6 +149,92 @@ def test_histogram_merge_two_ranks():
     assert res == [(0, True), (1, True)]
 
 
+SWEEP_SHAPES = [(256, 1024), (64, 512), (256, 1024), (128, 2048), (64, 512), (256, 1024), (512, 256), (128, 2048)]
+SWEEP_PASSES = [("int8", 8, None), ("int8_asym", 8, 32), ("fp8_e4m3", 8, 128)]
+
+
+def _sweep_weights():
+    g = torch.Generator(device="cuda").manual_seed(77)
+    return [(torch.randn(*s, generator=g, device="cuda") * 0.02).to(torch.bfloat16) for s in SWEEP_SHAPES]
+
+
+def _sweep_worker(rank, world, port, backend, q):
+    """One rank of the sharded sweep as bench.py runs it: SweepPlan over this rank's layers (two streams), the
+    record all-reduce and the joint percentile enqueued straight behind it, several steps in a row."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from quantization_amd.distributed import gather_records, joint_percentile, lpt_partition
+    from quantization_amd.report import RECORD_FIELDS, SweepPlan
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    ws = _sweep_weights()
+    mine = lpt_partition([w.numel() for w in ws], world)[rank]
+    plan = SweepPlan([ws[i] for i in mine], SWEEP_PASSES)
+    nl, width = len(ws), len(RECORD_FIELDS)
+    index = torch.as_tensor([p * nl + i for p in range(len(SWEEP_PASSES)) for i in mine], device=dev)
+    total = sum(w.shape[0] for w in ws)
+    for _ in range(3):
+        local = plan.run().reshape(-1, width)
+        if world > 1:
+            table = gather_records(index, local, nl * len(SWEEP_PASSES), width, dev)
+        else:   # one rank: the collective itself, enqueued behind the two-stream sweep
+            table = torch.zeros(nl * len(SWEEP_PASSES), width, dtype=torch.float64, device=dev)
+            table[index] = local
+            dist.all_reduce(table)
+        p99 = joint_percentile(plan.lists(0), 99.0, dtype=torch.float32, total=total, wide=True)
+    q.put((rank, table.cpu().numpy(), float(p99)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_sweep_ranks(world, backend):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + (7 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_sweep_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def _sweep_single_process():
+    from quantization_amd.report import SweepPlan
+    ws = _sweep_weights()
+    plan = SweepPlan(ws, SWEEP_PASSES)
+    rec = plan.run().cpu().numpy().reshape(len(SWEEP_PASSES) * len(ws), -1)
+    lists = np.concatenate([v.cpu().numpy() for v in plan.lists(0)]).astype(np.float64)
+    return rec, float(np.percentile(lists, 99))
+
+
+def test_sharded_sweep_two_ranks_equals_one():
+    """Two ranks (gloo standing in for RCCL, both on this GPU): record table and model-wide P99 of the sharded
+    sweep equal the single-process sweep bit for bit, with the collectives issued while the sweep's two streams
+    still hold work."""
+    want_rec, want_p99 = _sweep_single_process()
+    for rank, table, p99 in _run_sweep_ranks(2, "gloo"):
+        assert np.array_equal(table, want_rec), rank
+        assert p99 == want_p99, rank
+
+
+def test_rccl_collective_behind_two_stream_sweep():
+    """RCCL itself (one rank: every box has one GPU): an all-reduce enqueued right behind the sweep's two streams
+    completes and leaves the table unchanged."""
+    want_rec, want_p99 = _sweep_single_process()
+    (rank, table, p99), = _run_sweep_ranks(1, "nccl")
+    assert np.array_equal(table, want_rec)
+    assert p99 == want_p99
+
+
 def test_model_records_equals_per_layer_records():
     """The batched whole-model pass (layers grouped by shape, one fused launch per group, P99 of |err| selected
     inside it) gives the per-layer flow's records: percentiles bit for bit, sums exactly (same kernels, same
