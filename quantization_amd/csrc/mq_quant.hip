@@ -560,6 +560,18 @@ __device__ __forceinline__ h16x2 div_pk(uint32_t vw, const SegP& sp) {
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_fmaf(ra, sp.r, q0a)), "v"(__builtin_fmaf(rb, sp.r, q0b)));
   return as_h2(x);
 }
+// h(|v| / s) for both halves of vw: div_pk with the absolute value taken by the source modifier of the mixed
+// instructions (free), for the table formats, which round magnitudes
+__device__ __forceinline__ uint32_t div_pk_abs(uint32_t vw, const SegP& sp) {
+  float q0a, q0b, ra, rb;
+  asm("v_fma_mix_f32 %0, |%1|, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0a) : "v"(vw), "v"(sp.r));
+  asm("v_fma_mix_f32 %0, |%1|, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q0b) : "v"(vw), "v"(sp.r));
+  asm("v_fma_mix_f32 %0, -%1, %2, |%3| op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(q0a), "v"(sp.sf), "v"(vw));
+  asm("v_fma_mix_f32 %0, -%1, %2, |%3| op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(q0b), "v"(sp.sf), "v"(vw));
+  uint32_t x;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(x) : "v"(__builtin_fmaf(ra, sp.r, q0a)), "v"(__builtin_fmaf(rb, sp.r, q0b)));
+  return x;
+}
 // h(v / s) for both halves of vw in packed float16 arithmetic, four instructions per pair:
 //   v' = v P,  q0 = v' r,  rem = fma(-q0, s', v'),  q1 = fma(rem, r, q0)      s' = s P in [1, 2), r = RN16(1 / s')
 // P is a power of two, so v' / s' = v / s; it lifts the remainder out of the float16 subnormal range, where the
@@ -583,18 +595,19 @@ __device__ __forceinline__ h16x2 div_pk16(uint32_t vw, const SegP& sp) {
   const h16x2 rem = __builtin_elementwise_fma(-q0, as_h2(sp.pk_s), v1);
   return __builtin_elementwise_fma(rem, as_h2(sp.pk_r), q0);
 }
-// |nearest table value| for the two float16 quotients in xw, for a table WITHOUT subnormals; vw: the weights (the
-// quotient has their sign, and a zero quotient rounds to zero whatever its sign).  lut_round_pk without the sign
-// handling and without the upper clamp: the caller knows |x| <= (1 + 2^-9) * largest entry, which rounds to the
-// largest entry for up to 6 mantissa bits (the host sends tables with more to the general kernels).
+// |nearest table value| for the two float16 magnitudes |x| in xw (sign bits clear), for a table WITHOUT
+// subnormals; vw: the weights (x has their sign: a tie goes to the smaller VALUE, i.e. down for positive and up in
+// magnitude for negative x).  lut_round_pk without the sign handling and without the upper clamp: the caller
+// knows |x| <= (1 + 2^-9) * largest entry, which rounds to the largest entry for up to 6 mantissa bits (the host
+// sends tables with more to the general kernels).  Seven instructions per pair.
 __device__ __forceinline__ uint32_t lut_round_mag_pk(uint32_t xw, uint32_t vw, const LutConst& c) {
-  const uint32_t an = (xw & 0x7fff7fffu) + pk_shr_u16(dup16(15u), vw);  // |x| bits, + 1 for negative x
-  uint32_t r = (an + dup16(c.half - 1u)) & dup16(0xffffu << c.shift);
-  r = pk_max_u16(r, dup16(c.minpos));
-  uint32_t t;  // mid - an per half: negative iff |x| is past the 0 / minpos midpoint
-  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(t) : "v"(dup16(c.mid)), "v"(an));
+  // t = |x| bits + (1 for negative x) + half - 1: one v_add3_u32 (no carry leaves a half: t < 0x8000)
+  const uint32_t t = xw + pk_shr_u16(dup16(15u), vw) + dup16(c.half - 1u);
+  const uint32_t r = pk_max_u16(t & dup16(0xffffu << c.shift), dup16(c.minpos));
+  uint32_t d;  // (mid + half - 1) - t per half: negative iff |x| (+ 1) is past the 0 / minpos midpoint
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(dup16(c.mid + c.half - 1u)), "v"(t));
   uint32_t m;  // (the shift count from a register: an inline constant would reach the low half only)
-  asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(dup16(15u)), "v"(t));
+  asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(m) : "v"(dup16(15u)), "v"(d));
   return r & m;
 }
 // One lane's 8 elements, statistics only.  sse / sabs: float32 sums over these 8 elements are ADDED to the caller's
@@ -611,8 +624,8 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t vw = raw[k];
-    const h16x2 x = (PK16 && !MQ_IS_LUT(FMT)) ? div_pk16(vw, sp) : div_pk(vw, sp);
-    h16x2 e;
+    h16x2 x, e;
+    if constexpr (FMT != MQ_LUT_FP) x = (PK16 && !MQ_IS_LUT(FMT)) ? div_pk16(vw, sp) : div_pk(vw, sp);
     if constexpr (FMT == MQ_INT_SYM) {
       e = as_h2(vw) - ((x + magic) - magic) * s2;
     } else if constexpr (FMT == MQ_INT_ASYM) {
@@ -628,7 +641,7 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
       // entry (ties toward -inf), d is then 2 |v| (1 + 2^-11) and v - d needs 12 bits (13 float16 patterns per
       // scale binade for fp8_e4m3: tests/tools/sterbenz_exhaustive.c).  Plain float32 instructions issue at
       // 2.4 .. 2.6 cycles, so this costs ~3 cycles per pair more than the packed form.
-      const uint32_t dm = as_u32(as_h2(lut_round_mag_pk(as_u32(x), vw, p.lut)) * s2);
+      const uint32_t dm = as_u32(as_h2(lut_round_mag_pk(div_pk_abs(vw, sp), vw, p.lut)) * s2);
       float e0, e1;
       asm("v_fma_mix_f32 %0, -%1, 1.0, |%2| op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(e0) : "v"(dm), "v"(vw));
       asm("v_fma_mix_f32 %0, -%1, 1.0, |%2| op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(e1) : "v"(dm), "v"(vw));

@@ -14,13 +14,14 @@
  *
  * float16 operations are emulated exactly: a product of two float16 numbers is exact in float32; fma16 forms
  * a * b + c exactly in double (the operands span fewer than 53 bits on this domain, asserted) and rounds once,
- * through a round-to-odd float32.  Prints "pairs bad_rint bad_bits bad_recip inexact_double"; all but the first
- * must be 0.
+ * through a round-to-odd float32.  Prints "pairs bad_rint bad_bits bad_recip inexact_double bad_small"; all but the
+ * first must be 0.
  * Build: gcc -O2 -mf16c -mfma -fopenmp -ffp-contract=off div16_exhaustive.c -lm */
 #include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static inline float h2f(unsigned b) { return _cvtsh_ss((unsigned short)b); }
@@ -49,9 +50,17 @@ static inline float fma16(float a, float b, float c, long* inexact) {
   return hr(round_odd_f32(s));
 }
 
-int main(void) {
+/* argv: J QMAX (defaults 0 600).  J > 0 is the table formats' variant: s' = s 2^k 2^J lies in [2^J, 2^(J+1)) (the
+ * weight takes two power-of-two factors, P1 P2 = 2^(k+J), since 2^(k+J) itself may exceed float16), which moves the
+ * exactness threshold down to T = 2^(-4-J); QMAX bounds the quotient.  Sixth number printed: quotients below T whose
+ * q1 is not below T as well (must be 0: then every table whose smallest 0 / entry midpoint is >= T rounds q1 and
+ * h(v / s) alike). */
+int main(int argc, char** argv) {
   const unsigned S_LO = 0x0200u, S_HI = 0x70E2u;
-  long pairs = 0, bad_rint = 0, bad_bits = 0, bad_recip = 0, inexact = 0;
+  const int J = argc > 1 ? atoi(argv[1]) : 0;
+  const float QMAX = argc > 2 ? (float)atof(argv[2]) : 600.0f;
+  const float T = ldexpf(1.0f, -4 - J);
+  long pairs = 0, bad_rint = 0, bad_bits = 0, bad_recip = 0, inexact = 0, bad_small = 0;
   for (unsigned m = 0; m < 1024; ++m) {
     const float s1 = h2f(0x3c00u | m);
     const double exact = 1.0 / (double)s1;
@@ -59,26 +68,28 @@ int main(void) {
     const unsigned want = f2h(f);
     if (f2h(nextafterf(f, 0.0f)) != want || f2h(nextafterf(f, 2.0f)) != want) ++bad_recip;
   }
-#pragma omp parallel for reduction(+ : pairs, bad_rint, bad_bits, inexact) schedule(dynamic, 64)
+#pragma omp parallel for reduction(+ : pairs, bad_rint, bad_bits, inexact, bad_small) schedule(dynamic, 64)
   for (unsigned sb = S_LO; sb <= S_HI; ++sb) {
     const float s = h2f(sb);
     int e;
     frexpf(s, &e);
     const int k = 1 - e;
-    const float P = ldexpf(1.0f, k), s1 = s * P; /* exact */
+    const int k1 = (k + J + 1) / 2, k2 = k + J - k1;      /* both factors are float16 numbers: k + J <= 15 + J */
+    const float P1 = ldexpf(1.0f, k1), P2 = ldexpf(1.0f, k2), s1 = ldexpf(s, k + J); /* exact */
     const float r = hr((float)(1.0 / (double)s1));
     for (unsigned vb = 0; vb < 0x7c00u; ++vb) {
       const float v = h2f(vb), want = hr(v / s);
-      if (!(want <= 600.0f)) break; /* the quotient grows with v */
-      const float v1 = hr(v * P);
+      if (!(want <= QMAX)) break; /* the quotient grows with v */
+      const float v1 = hr(hr(v * P1) * P2);
       const float q0 = hr(v1 * r);
       const float rem = fma16(-q0, s1, v1, &inexact);
       const float q1 = fma16(rem, r, q0, &inexact);
       ++pairs;
       if (rintf(q1) != rintf(want)) ++bad_rint;
-      if (want >= 0.0625f && f2h(q1) != f2h(want)) ++bad_bits;
+      if (want >= T && f2h(q1) != f2h(want)) ++bad_bits;
+      if (want < T && !(q1 < T)) ++bad_small;
     }
   }
-  printf("%ld %ld %ld %ld %ld\n", pairs, bad_rint, bad_bits, bad_recip, inexact);
+  printf("%ld %ld %ld %ld %ld %ld\n", pairs, bad_rint, bad_bits, bad_recip, inexact, bad_small);
   return 0;
 }
