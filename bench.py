@@ -40,6 +40,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 MODEL_OF = {"llama8b": "llama-3-8b", "llama70b": "llama-3-70b", "tinyllama": "tinyllama-1.1b"}
 GROUPS = (None, 32, 64, 128)
+# Order of the passes in a model sweep: the selections of a pass run under the launches of the next one, only the
+# last pass's are exposed -- so the longest lists (g = 32) go first and the per-channel pass, whose lists are the
+# rows of a layer, goes last.
+SWEEP_ORDER = (32, 64, 128, None)
 REFERENCE_BUILD_CONTAINER = {
     # the reference itself (imported quant_weight._int_quant_meta on torch CPU + the scripts' numpy arithmetic) on
     # the c2 unit of work, timed in the build container by scratch/ref_time.py; /root/reference does not exist
@@ -109,9 +113,9 @@ class ModelSweep:
         self.dtype = torch.float16 if name == "tinyllama" else torch.bfloat16
         if name == "llama70b":
             fmts = [("int8", 8), ("int8_asym", 8), ("fp8_e4m3", 8), ("fp8_e3m4", 8)]
-            self.passes = [(f, b, gs) for f, b in fmts for gs in GROUPS]
+            self.passes = [(f, b, gs) for f, b in fmts for gs in SWEEP_ORDER]
         elif name == "llama8b":
-            self.passes = [("int8", 8, gs) for gs in GROUPS]
+            self.passes = [("int8", 8, gs) for gs in SWEEP_ORDER]
         else:
             self.passes = [("int8", 8, None)]
         sizes = [r * c for _, (r, c) in self.layers]
@@ -131,8 +135,9 @@ class ModelSweep:
         self.n_layers = len(self.layers)
         self.plan = None
         self.overlap = True   # selections of pass k on a second stream under the launches of pass k + 1
-        f0, _, g0 = self.passes[0]   # the lists of the first pass feed the model-wide percentile
-        self.total_vectors = sum(r if g0 is None else r * c // g0 for _, (r, c) in self.layers)
+        # the per-channel lists of the first format feed the model-wide percentile
+        self.joint_pass = next(k for k, (_, _, gs) in enumerate(self.passes) if gs is None)
+        self.total_vectors = sum(r for _, (r, c) in self.layers)
         self.index = torch.as_tensor([p * self.n_layers + i for p in range(len(self.passes)) for i in self.mine],
                                      dtype=torch.int64, device=device)
         fm = ", ".join(sorted({f for f, _, _ in self.passes}))
@@ -152,11 +157,11 @@ class ModelSweep:
         local, vecs = None, []
         if self.weights:
             # every pass of the sweep over this rank's resident layers (launch descriptors and buffers prepared once);
-            # the per-channel lists of the first pass feed the model-wide percentile
+            # the per-channel lists of the first format feed the model-wide percentile
             if self.plan is None:
                 self.plan = SweepPlan(self.weights, self.passes)
             local = self.plan.run(overlap=self.overlap).reshape(-1, len(RECORD_FIELDS))
-            vecs = self.plan.lists(0)
+            vecs = self.plan.lists(self.joint_pass)
         # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
         table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
         # ... and the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists
@@ -187,6 +192,9 @@ class Workload:
             return (x * 0.02).to(dtype)
 
         self.compare = None
+        self.sweep = None     # llama70b_shard: (weights, passes) of a report.SweepPlan
+        self.plan = None
+        self.overlap = True
         self.batches = []  # (stacked weights [B, rows, cols], fmt, datatype, gs, outputs dict)
         self.results = {}
         if name == "c2":
@@ -212,8 +220,9 @@ class Workload:
                              "outlier masks of compare.py")
             else:
                 passes = [(f, d, gs) for f, d in ((_lib.INT_SYM, None), (_lib.INT_ASYM, None), (_lib.LUT_FP, "fp8_e4m3"),
-                                                  (_lib.LUT_FP, "fp8_e3m4")) for gs in GROUPS]
+                                                  (_lib.LUT_FP, "fp8_e3m4")) for gs in SWEEP_ORDER]
                 outs = stats
+                self.sweep = ([], [(n, 8, gs) for n in ("int8", "int8_asym", "fp8_e4m3", "fp8_e3m4") for gs in SWEEP_ORDER])
                 self.desc = (f"llama70b_shard: 1/8 of Llama-3-70B's linear layers ({len(shapes)} tensors, 17.1 GB bf16 {dist_name}): "
                              "int8 sym / asym, fp8_e4m3, fp8_e3m4 x per-channel / g=32 / 64 / 128 error statistics "
                              "(per-vector/tensor MSE, sum|err|, exact P99 of the per-vector MSE)")
@@ -225,6 +234,8 @@ class Workload:
                     b = min(32, cnt - lo)
                     g.manual_seed(1000 * rank + 17 * k + lo)
                     w = draw((b, r, c), dt)
+                    if self.sweep is not None:
+                        self.sweep[0].extend(w.unbind(0))
                     first = len(self.batches)
                     for fmt, table, gs in passes:
                         self.batches.append((w, fmt, table, gs, outs))
@@ -257,6 +268,12 @@ class Workload:
         import torch
         from quantization_amd.error_metrics import percentile_rows
         from quantization_amd.fused import QuantResult, quantize_batch
+        if self.sweep is not None:
+            # the model-sweep entry point over this GPU's resident tensors: records [passes, tensors, fields]
+            if self.plan is None:
+                from quantization_amd.report import SweepPlan
+                self.plan = SweepPlan(*self.sweep)
+            return self.plan.run(overlap=self.overlap)
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
             res = self.results.get(k)
@@ -368,6 +385,20 @@ def roofline(algo_bytes_per_step, steps, kern_ms, launches, kernel_desc, traffic
             "algorithmic_bytes_per_launch": int(per_launch)}
 
 
+def launch_alone(wl, device, dist, world, reserve, algo_bytes):
+    """The sweep's quantize launches with nothing else on the chip, outside the timed region: in the timed steps the
+    selections of the previous pass run on a second stream and share the HBM with them, which lengthens each launch."""
+    wl.overlap = False
+    _, _, k_iso, n_iso = timed_run(wl.step, 2, 1, device, dist, world, reserve)
+    wl.overlap = True
+    if not n_iso:
+        return None
+    iso = roofline(algo_bytes, 2, k_iso, n_iso, "", None)
+    return {"avg_launch_us": iso["avg_launch_us"], "achieved": iso["achieved"], "frac": iso["frac"],
+            "note": "the same launches in 2 extra untimed steps with the selections kept on the same stream: in the "
+                    "timed steps the previous pass's selections run concurrently on a second stream and share the HBM"}
+
+
 def traffic_for(name):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -421,13 +452,8 @@ def main():
         total_weight_bytes, local_algo, reserve = wl.weight_bytes, wl.algo_bytes, wl.launches
     wall, gpu_ms, kern_ms, kern_launches = timed_run(wl.step, args.steps, args.warmup, device, dist, world, reserve)
     isolated = None
-    if sharded:
-        # the same launches with nothing else on the chip (outside the timed region): in the timed steps the
-        # selections of the previous pass share the HBM with them, which lengthens each launch
-        wl.overlap = False
-        _, _, k_iso, n_iso = timed_run(wl.step, 2, 1, device, dist, world, reserve)
-        wl.overlap = True
-        isolated = (k_iso, n_iso)
+    if sharded or getattr(wl, "sweep", None) is not None:
+        isolated = launch_alone(wl, device, dist, world, reserve, local_algo)
 
     # per-rank shares, for the record
     shares = None
@@ -463,12 +489,8 @@ def main():
             "roofline": roofline(local_algo, args.steps, kern_ms, kern_launches, wl.kernel_desc + " (rank 0)",
                                  traffic_for(args.workload)),
         }
-        if sharded and isolated and isolated[1]:
-            iso = roofline(local_algo, 2, isolated[0], isolated[1], "", None)
-            out["roofline"]["launch_alone"] = {
-                "avg_launch_us": iso["avg_launch_us"], "achieved": iso["achieved"], "frac": iso["frac"],
-                "note": "the same launches in 2 extra untimed steps with the selections kept on the same stream: in the "
-                        "timed steps the previous pass's selections run concurrently on a second stream and share the HBM"}
+        if isolated:
+            out["roofline"]["launch_alone"] = isolated
         if sharded:
             out["config"].update({
                 "backend": backend if world > 1 else "none (one rank)",
@@ -490,6 +512,8 @@ def main():
                 "ms_per_step": round(wall2 / steps * 1e3, 4), "workload": w2.desc,
                 "weight_bytes_per_step": int(w2.weight_bytes),
                 "roofline": roofline(w2.algo_bytes, steps, k2, n2, w2.kernel_desc, traffic_for(name))}
+            if w2.sweep is not None:
+                out["extra"][name]["roofline"]["launch_alone"] = launch_alone(w2, device, None, 1, w2.launches, w2.algo_bytes)
             del w2
             torch.cuda.empty_cache()
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
