@@ -412,13 +412,34 @@ MIXED_LISTS = {
 _SEARCH_VALUES = dict(TABLE_LISTS, int3=MX_TABLES["mx_int3"], int4=MX_TABLES["mx_int4"])
 
 
+_TORCH_SCALAR_NAMES = {torch.bfloat16: "BFloat16", torch.float32: "Float", torch.float64: "Double"}
+
+
+def search_dtype_check(dtype) -> None:
+    """search_datatype accepts float16 weights only, and so does the reference in effect: its running-best error
+    tensor and its result take the weight's dtype while the candidates are float16 and their errors float32, so the
+    masked assignments of quant_weight.py:644-645 raise for every other dtype.  Same exception, same message
+    (recorded from the reference in tests/golden/search_errors.json): the error assignment (:644) fails first when
+    the weight is bfloat16 (float32 errors into a bfloat16 tensor); for float32 / float64 weights that one passes
+    or promotes and the candidate assignment (:645) fails."""
+    if dtype == torch.float16:
+        return
+    if dtype == torch.bfloat16:
+        dst, src = "BFloat16", "Float"
+    elif dtype in _TORCH_SCALAR_NAMES:
+        dst, src = _TORCH_SCALAR_NAMES[dtype], "Half"
+    else:
+        raise RuntimeError(f"search_datatype: unsupported weight dtype {dtype}")
+    raise RuntimeError(f"Index put requires the source and destination dtypes match, got {dst} for the destination "
+                       f"and {src} for the source.")
+
+
 @torch.no_grad()
 def search_tables(w: torch.Tensor, tables, group_size=None, want_choice=False):
     """Per row (or group) of a float16 ROCm tensor [rows, cols], the first of `tables` (value lists) with the
-    smallest float16 mean squared error (mq_search_tables).  -> deq float16 [rows, cols] (, choice uint8 [nseg])."""
-    if w.dtype != torch.float16:
-        raise NotImplementedError("the datatype search follows the reference's float16 arithmetic: pass a "
-                                  "float16 weight")
+    smallest float16 mean squared error (mq_search_tables).  -> deq float16 [rows, cols] (, choice uint8 [nseg]).
+    Other dtypes raise as the reference does (search_dtype_check)."""
+    search_dtype_check(w.dtype)
     if not w.is_cuda:
         raise RuntimeError("search_tables() expects a ROCm device tensor")
     rows, cols = w.shape

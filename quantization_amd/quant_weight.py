@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .fused import (LUT_FORMATS, MIXED_LISTS, MX_TABLES, TABLE_LISTS, _SEARCH_VALUES, quantize, quantize_batch,
-                    quantize_table, require_device, search_tables)
+                    quantize_table, require_device, search_dtype_check, search_tables)
 
 # names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
 # ValueError / AssertionError behaviour for unknown names
@@ -132,6 +132,7 @@ def search_datatype(w_fp16, wq_bits: int = 4, datatype: str = "mixed_bitmod", gr
         raise ValueError(f"unknown mixed datatype {datatype!r}")
     K, C = w_fp16.size()
     dev = w_fp16.device
+    search_dtype_check(w_fp16.dtype)   # (float16 only, as the reference: its masked assignments raise otherwise)
     tables = [_SEARCH_VALUES[name] for name in MIXED_LISTS[(wq_bits, datatype)]]
     return search_tables(require_device(w_fp16), tables, group_size).reshape(K, C).to(dev)
 

@@ -356,6 +356,19 @@ def gen_search():
                     arrays[f"out/{name}/{wq_bits}/{kind}/{gs_key(gs)}"] = bits16(d)
     np.savez_compressed(os.path.join(HERE, "quant_search.npz"), **arrays)
     print("quant_search.npz", len(arrays), "arrays")
+    # what the reference does with weights that are not float16: the exception type and message per dtype
+    errors = {}
+    for dt in (torch.bfloat16, torch.float32, torch.float64):
+        w = (torch.randn(8, 256, generator=gen) * 0.02).to(dt)
+        for gs in (None, 64):
+            try:
+                qw.search_datatype(w, wq_bits=4, datatype="mixed_bitmod", group_size=gs)
+                errors[f"{str(dt).split('.')[-1]}/{gs_key(gs)}"] = None
+            except Exception as e:   # noqa: BLE001 -- the point is to record whatever it raises
+                errors[f"{str(dt).split('.')[-1]}/{gs_key(gs)}"] = [type(e).__name__, str(e)]
+    with open(os.path.join(HERE, "search_errors.json"), "w") as f:
+        json.dump(errors, f, indent=1, sort_keys=True)
+    print("search_errors.json", errors)
 
 
 QUANT_MODEL_CASES = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp4", 4)]

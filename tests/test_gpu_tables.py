@@ -2,6 +2,8 @@
 the imported reference: fp3 / flint4 / flint5 and the *_er_* / *_ea_* lists, fp8_e5m2 (float32 results) and
 quant_mx.  Bit-exact (a NaN matches any NaN); error statistics against a float64 sum of the same float32 errors."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -156,8 +158,17 @@ def test_table_errors_and_model_routes(qa):
         qw.quant_model(nn.Sequential(nn.Linear(8, 8)).half().cuda(), 4, "flint4", None)   # as in the reference
     with pytest.raises(ValueError):
         qw.search_datatype(w, 5, "mixed_er", None)
-    with pytest.raises(NotImplementedError):
-        qw.search_datatype(w.float(), 4, "mixed_er", None)
+    # weights that are not float16: the reference's own exception and message (tests/golden/search_errors.json)
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "search_errors.json")) as f:
+        recorded = json.load(f)
+    for key, (exc, msg) in recorded.items():
+        dt = getattr(torch, key.split("/")[0])
+        gs = None if key.endswith("none") else int(key.split("/")[1])
+        assert exc == "RuntimeError"
+        with pytest.raises(RuntimeError) as info:
+            qw.search_datatype((torch.randn(8, 256) * 0.02).to(dt).cuda(), 4, "mixed_bitmod", gs)
+        assert str(info.value) == msg
     model = nn.Sequential(nn.Linear(128, 64)).half().cuda()
     w0 = model[0].weight.data.clone()
     qw.quant_model(model, 3, "mixed_ant", 32)

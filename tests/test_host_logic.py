@@ -109,3 +109,28 @@ def test_sharded_gather_world2_gloo():
         assert p.exitcode == 0
     assert all(ok for _, _, ok in res)
     assert sorted(res[0][1] + res[1][1]) == [0, 1, 2, 3, 4] and res[0][1] and res[1][1]
+
+
+def test_search_datatype_rejects_other_dtypes_as_the_reference_does():
+    """search_datatype on bfloat16 / float32 / float64 weights: the reference's masked assignments raise
+    (quant_weight.py:644-645); exception type and message recorded from the imported reference by
+    tests/golden/gen_golden.py (search_errors.json).  The check precedes every device call."""
+    import json
+    import os
+    import pytest
+    import torch
+    pytest.importorskip("ctypes")
+    try:
+        from quantization_amd import quant_weight as qw
+    except ImportError:
+        pytest.skip("libmq.so is not built")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "search_errors.json")) as f:
+        recorded = json.load(f)
+    assert len(recorded) == 6
+    for key, (exc, msg) in recorded.items():
+        dt = getattr(torch, key.split("/")[0])
+        gs = None if key.endswith("none") else int(key.split("/")[1])
+        with pytest.raises(RuntimeError) as info:
+            qw.search_datatype(torch.zeros(8, 256, dtype=dt), 4, "mixed_bitmod", gs)
+        assert exc == "RuntimeError" and str(info.value) == msg
