@@ -25,10 +25,15 @@ Files written:
                         nn.Sequential of four float16 nn.Linear: weights before / after, every registered buffer
                         (bytes, dtype, shape) and the module class names, for int8 / int8_asym / int4_asym /
                         fp8_e4m3 / fp4 x {per-channel, g=64, per-tensor}
+  onnx/                 model files written by PyTorch's ONNX serializer (plain and quantized by the reference's
+                        quant_model), every parameter's bits, the MatMul / Gemm weight names
+  search_errors.json    what search_datatype raises for weights that are not float16
   error_stats.json      outputs of the reference's quantizers + the analysis scripts' numpy
                         arithmetic on seeded 512x1024 inputs (scalars and digests only)
 """
+import contextlib
 import hashlib
+import io
 import json
 import os
 import sys
@@ -371,6 +376,80 @@ def gen_search():
     print("search_errors.json", errors)
 
 
+def gen_onnx():
+    """ONNX files written by PyTorch's own exporter (the TorchScript exporter's C++ serializer, the writer behind the
+    reference's export_and_quant.py; its internals are called directly because torch.onnx.export() insists on the
+    `onnx` package, which is not installed): fixtures for the initializer reader that do not come from this
+    repository's test writer.  Stored: the model files and, per file, every parameter's bits by name."""
+    import warnings
+    import torch.nn as nn
+    from torch.onnx._internal.torchscript_exporter import _globals as G, utils as U
+    warnings.filterwarnings("ignore")
+    out_dir = os.path.join(HERE, "onnx")
+    os.makedirs(out_dir, exist_ok=True)
+
+    class Block(nn.Module):   # Linear layers with and without bias, an embedding (Gather), a weight used twice
+        def __init__(self):
+            super().__init__()
+            self.embed = nn.Embedding(50, 32)
+            self.q_proj = nn.Linear(32, 32, bias=False)
+            self.up = nn.Linear(32, 96)
+            self.down = nn.Linear(96, 32, bias=False)
+            self.norm = nn.LayerNorm(32)
+
+        def forward(self, ids):
+            h = self.embed(ids)
+            h = h + self.q_proj(self.norm(h))
+            return self.down(torch.relu(self.up(h)))
+
+    arrays, meta = {}, {}
+    # (file, dtype, constant folding, the reference's quant_model arguments or None): the last two are the
+    # reference's own quantized exports of the first model -- _LinearDump modules with weight_q / weight_scale /
+    # weight_zp buffers -- in the directory layout quant_error_multi_weight.py parses (:41-52)
+    cases = (("block_f16", torch.float16, False, None), ("block_f32_folded", torch.float32, True, None),
+             ("tree/per-group/int8_asym/w_8_gs_32/model", torch.float16, False, (8, "int8_asym", 32)),
+             ("tree/per-channel/fp8_e4m3/w_8_gs_none/model", torch.float16, False, (8, "fp8_e4m3", None)))
+    for name, dtype, fold, qcfg in cases:
+        torch.manual_seed(23)
+        m = Block().to(dtype).eval()
+        if qcfg is not None:
+            qw.time.sleep = lambda *_: None      # (it only paces the prints)
+            with contextlib.redirect_stdout(io.StringIO()):
+                qw.quant_model(m, *qcfg)
+        os.makedirs(os.path.dirname(os.path.join(out_dir, name)), exist_ok=True)
+        ids = torch.randint(0, 50, (2, 7))
+        G.GLOBALS.export_onnx_opset_version = 17
+        G.GLOBALS.operator_export_type = torch.onnx.OperatorExportTypes.ONNX
+        with torch.no_grad():
+            graph, params, _ = U._model_to_graph(m, (ids,), False, ["ids"], ["y"], torch.onnx.OperatorExportTypes.ONNX,
+                                                 do_constant_folding=fold, training=torch.onnx.TrainingMode.EVAL,
+                                                 dynamic_axes={})
+        proto = graph._export_onnx(params, 17, {}, False, torch.onnx.OperatorExportTypes.ONNX, True, False, {}, True,
+                                   "", {})[0]
+        with open(os.path.join(out_dir, name + ".onnx"), "wb") as f:
+            f.write(proto)
+        for k, v in params.items():
+            a = v.detach().cpu()
+            arrays[f"{name}/{k}"] = a.view(torch.int16).numpy() if a.dtype == torch.float16 else a.numpy()
+        # MatMul / Gemm weight operands as the graph names them (second input, possibly through one Transpose)
+        weights = []
+        producers = {o.debugName(): n for n in graph.nodes() for o in n.outputs()}
+        for n in graph.nodes():
+            if n.kind() in ("onnx::MatMul", "onnx::Gemm"):
+                w = list(n.inputs())[1]
+                src = producers.get(w.debugName())
+                if src is not None and src.kind() == "onnx::Transpose":
+                    w = list(src.inputs())[0]
+                if w.debugName() in params:
+                    weights.append(w.debugName())
+        meta[name] = {"bytes": len(proto), "sha256": hashlib.sha256(proto).hexdigest(), "params": sorted(params),
+                      "matmul_gemm_weights": sorted(set(weights)), "torch": torch.__version__}
+    np.savez_compressed(os.path.join(out_dir, "params.npz"), **arrays)
+    with open(os.path.join(out_dir, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("onnx/", meta)
+
+
 QUANT_MODEL_CASES = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp4", 4)]
 QUANT_MODEL_GROUPS = [None, 64, -1]
 
@@ -485,6 +564,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "specials":
         gen_specials()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "onnx":
+        gen_onnx()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "search":
         gen_search()

@@ -1,5 +1,6 @@
-"""The ONNX initializer reader (include/mq_onnx.h) against files written by tests/onnx_writer.py.  No `onnx`
-package is available, so the file format follows onnx.proto as published; host-only code, runs without a GPU."""
+"""The ONNX initializer reader (include/mq_onnx.h) against files written by tests/onnx_writer.py (no `onnx` package
+is available, so that writer follows onnx.proto as published) and against files written by PyTorch's own exporter
+(tests/golden/onnx/); host-only code, runs without a GPU."""
 import os
 
 import numpy as np
@@ -49,6 +50,34 @@ def test_reader_finds_weights_and_bytes(io, tmp_path):
             assert got.tobytes() == arr.tobytes(), name
 
 
+def test_reader_on_files_written_by_pytorch(io):
+    """Files from PyTorch's own ONNX serializer (tests/golden/onnx/, made by gen_golden.py onnx: the TorchScript
+    exporter behind the reference's export script), not from this repository's test writer: every parameter comes
+    back by name with its bits and shape, and the MatMul / Gemm weight selection -- directly or through one
+    Transpose, pre-transposed constants after folding -- matches what the exporter's graph says."""
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
+    with open(os.path.join(gold, "meta.json")) as f:
+        meta = json.load(f)
+    params = np.load(os.path.join(gold, "params.npz"))
+    assert len(meta) == 4
+    for name, m in meta.items():
+        path = os.path.join(gold, name + ".onnx")
+        assert os.path.getsize(path) == m["bytes"]
+        with io.OnnxWeights(path) as ow:
+            names = ow.names()
+            assert set(m["params"]) <= set(names)
+            assert sorted(ow.compute_weights()) == m["matmul_gemm_weights"]
+            for k in m["params"]:
+                want = np.ascontiguousarray(params[f"{name}/{k}"])   # (folded constants are stored transposed)
+                got = np.ascontiguousarray(ow.array(k))
+                assert tuple(ow.shape(k)) == want.shape, (name, k)
+                if got.dtype == np.float16:
+                    assert want.dtype == np.int16 and np.array_equal(got.view(np.int16), want), (name, k)
+                else:
+                    assert got.dtype == want.dtype and np.array_equal(got.view(np.uint8), want.view(np.uint8)), (name, k)
+
+
 def test_reader_errors(io, tmp_path):
     with pytest.raises(OSError):
         io.OnnxWeights(str(tmp_path / "missing.onnx"))
@@ -89,6 +118,59 @@ def test_compare_onnx_report(io, tmp_path, oracle):
     out = tmp_path / "report.csv"
     report.write_csv(rows, str(out))
     assert out.read_text().splitlines()[0] == "initializer,datatype,granularity,bits,mse_tensor,mse_rep,mse_p99"
+
+
+@pytest.mark.gpu
+def test_compare_onnx_on_the_reference_quantized_exports(io, oracle):
+    """quant_error_multi_weight.py's flow on PyTorch-written files: the float16 model and the same model after the
+    REFERENCE's quant_model (tests/golden/onnx/tree/..., _LinearDump modules exported with their buffers).
+    (1) compare_onnx's rows against the scripts' numpy arithmetic on the stored parameters; (2) this package's
+    quant_model on the same float16 weights reproduces every weight / weight_q / weight_scale / weight_zp the
+    reference exported, bit for bit."""
+    import json
+    import torch
+    import torch.nn as nn
+    from quantization_amd import quant_weight as qw, report
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "onnx")
+    with open(os.path.join(gold, "meta.json")) as f:
+        meta = json.load(f)
+    params = np.load(os.path.join(gold, "params.npz"))
+    base = os.path.join(gold, "block_f16.onnx")
+    for name, m in meta.items():
+        if not name.startswith("tree/"):
+            continue
+        qpath = os.path.join(gold, *name.split("/")) + ".onnx"
+        grouping, dtype, bits, gs = report.parse_quant_config(qpath)
+        rows = report.compare_onnx(base, qpath, form="multi")
+        assert sorted(r["initializer"] for r in rows) == m["matmul_gemm_weights"]
+        for r in rows:
+            a = params[f"block_f16/{r['initializer']}"].view(np.float16).astype(np.float32)
+            b = params[f"{name}/{r['initializer']}"].view(np.float16).astype(np.float32)
+            want = oracle.compute_errors_multi(a, b, grouping, gs)
+            assert (r["datatype"], r["granularity"], r["bits"]) == (dtype, grouping, bits)
+            for k in ("mse_tensor", "mse_rep", "mse_p99"):
+                assert abs(r[k] - want[k]) <= 1e-6 * abs(want[k]), (name, r["initializer"], k)
+        # (2) the same model through this package's quant_model
+        model = nn.ModuleDict({k: nn.Linear(*reversed(params[f"block_f16/{k}.weight"].shape), bias=False)
+                               for k in ("q_proj", "up", "down")}).half().cuda()
+        for k in ("q_proj", "up", "down"):
+            w = torch.from_numpy(params[f"block_f16/{k}.weight"].view(np.float16).copy())
+            model[k].weight.data = w.cuda()
+        import contextlib
+        import io as _io
+        with contextlib.redirect_stdout(_io.StringIO()):
+            qw.quant_model(model, bits, dtype, gs)
+        for k in ("q_proj", "up", "down"):
+            for buf in ("weight", "weight_q", "weight_scale", "weight_zp"):
+                key = f"{name}/{k}.{buf}"
+                if key not in params:
+                    assert not hasattr(model[k], buf)
+                    continue
+                got = getattr(model[k], buf).detach().cpu().numpy()
+                want = params[key]
+                want = want.view(np.float16) if want.dtype == np.int16 else want
+                assert got.dtype == want.dtype and got.shape == want.shape, (key, got.dtype, want.dtype, got.shape)
+                assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(want).view(np.uint8)), key
 
 
 @pytest.mark.gpu
