@@ -355,9 +355,12 @@ __device__ __forceinline__ half_t div_h_full(float vf, const SegP& sp) {
 // amax: sign-cleared float16 bits
 __device__ __forceinline__ SegP params_absmax(uint32_t amax_bits, const QuantParams& p) {
   SegP sp;
-  finish_params(sp, clamp_scale(div_qmax(h_from_bits(amax_bits), p)));
+  const half_t s0 = div_qmax(h_from_bits(amax_bits), p);
+  finish_params(sp, clamp_scale(s0));
   sp.zp = (half_t)0;
-  sp.slow = amax_bits >= 0x7c00u;  // inf or NaN in the segment
+  // inf or NaN in the segment; or a scale cut down to the upper clamp (bit widths of 2 and 3 with values above
+  // 1e4 * qmax): then |v / s| exceeds qmax and the clamp of the codes, which the fast path leaves out, acts
+  sp.slow = amax_bits >= 0x7c00u || s0 > h_from_bits(0x70E2u);
   if (sp.slow) finish_params(sp, clamp_scale((half_t)((float)h_from_bits(amax_bits) / p.qmax)));
   return sp;
 }

@@ -1,6 +1,7 @@
 """GPU: a few seconds of the randomised differential runs (tests/fuzz_stats.py: statistics kernels against the CPU
-oracle; tests/fuzz_select.py: percentile selection against numpy) with fixed seeds.  Longer runs:
-`python tests/fuzz_stats.py 90 1`, `python tests/fuzz_select.py 120 1`."""
+oracle; tests/fuzz_quant.py: the general kernels, every output, against the CPU oracle; tests/fuzz_select.py:
+percentile selection against numpy) with fixed seeds, and the cases those runs have found.  Longer runs:
+`python tests/fuzz_stats.py 90 1`, `python tests/fuzz_quant.py 100 1`, `python tests/fuzz_select.py 120 1`."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -14,3 +15,35 @@ def test_statistics_kernels_random_cases(oracle):
 def test_percentile_selection_random_cases():
     import fuzz_select
     assert fuzz_select.run(8.0, 54321) > 20
+
+
+def test_general_kernels_random_cases(oracle):
+    import fuzz_quant
+    assert fuzz_quant.run(8.0, 777) > 100
+
+
+def test_scale_cut_to_the_upper_clamp_keeps_the_code_clamp(oracle):
+    """Found by fuzz_quant: symmetric 2- / 3-bit formats on values above 1e4 * qmax.  The scale is cut down to the
+    clamp's upper bound (float16 0x70E2), |v / s| then exceeds qmax and clamp(rint(x), -qmax, qmax)
+    (quant_weight.py:262-263) acts -- on every grouping, float16 / bfloat16 / float32 weights."""
+    import numpy as np
+    import torch
+    import golden_util as gu
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(24, 2048, generator=g) * 9000.0
+    w[3, 5], w[7, 9], w[11, 100] = 65504.0, -64000.0, 31000.0
+    for dt, odt in ((torch.float16, oracle.F16), (torch.bfloat16, oracle.BF16), (torch.float32, oracle.F32)):
+        wt = w.to(dt)
+        raw = wt.numpy() if dt == torch.float32 else wt.view(torch.int16).numpy().view(np.uint16)
+        for bits in (2, 3):
+            for gs in (None, 64, 16, -1):
+                exp = oracle.quantize(raw, odt, fmt=oracle.INT_SYM, bits=bits, group_size=gs)
+                assert (exp["scale"] == 0x70E2).any()
+                res = quantize(wt.cuda(), _lib.INT_SYM, bits, gs, None, deq=True, codes=True, scale=True)
+                b16 = lambda t: t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16).reshape(-1)
+                what = (str(dt), bits, gs)
+                assert gu.same_f16_bits(b16(res.scale), exp["scale"].reshape(-1)), what
+                assert gu.same_f16_bits(b16(res.deq), exp["deq"].reshape(-1)), what
+                assert np.array_equal(res.codes.cpu().numpy().reshape(-1).view(np.uint8), exp["q"].reshape(-1)), what
