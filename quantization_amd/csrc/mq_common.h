@@ -31,8 +31,15 @@ __device__ __forceinline__ half_t h_from_bits(uint32_t b) { return __builtin_bit
 __device__ __forceinline__ uint32_t h_bits(half_t h) { return (uint32_t)__builtin_bit_cast(uint16_t, h); }
 __device__ __forceinline__ float f_from_bits(uint32_t b) { return __builtin_bit_cast(float, b); }
 __device__ __forceinline__ uint32_t f_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
-// float32 -> float16, round to nearest even (v_cvt_f16_f32 under the default rounding mode)
-__device__ __forceinline__ uint32_t f2h_bits(float f) { return h_bits((half_t)f); }
+// float32 -> float16, round to nearest even (v_cvt_f16_f32 under the default rounding mode).  The empty asm pins
+// the argument down as a float32 VALUE: without it the compiler folds a multiply or fma that produces f into
+// v_fma_mixlo_f16, which rounds the exact product ONCE to float16, while the float32 paths of the reference
+// round twice -- (q * scale) is a float32 tensor before .to(torch.float16) -- and the two differ on float16
+// subnormal ties (0.234375 * 1.402537e-4 = 551.4999.. units of 2^-24: 551 fused, 552 in two steps).
+__device__ __forceinline__ uint32_t f2h_bits(float f) {
+  asm("" : "+v"(f));
+  return h_bits((half_t)f);
+}
 
 // Deterministic sum over the 64 lanes of a wave (fixed butterfly order); every lane gets the result.
 __device__ __forceinline__ double wave_sum(double v) {

@@ -26,6 +26,21 @@ LUT_SUBNORMAL = {"fp4", "fp5", "fp5_e2m2", "fp5_e3m1", "fp6", "fp6_e2m3", "fp6_e
 
 
 
+def lut_values(datatype: str):
+    """The value list of a closed-form table format (LUT_FORMATS), ascending -- what the reference spells out as a
+    literal list (quant_weight.py:9-138); pinned against those lists by tests/golden/lut_tables.json."""
+    E, M, bias = LUT_FORMATS[datatype]
+    pos = []
+    if datatype in LUT_SUBNORMAL:
+        pos += [m * 2.0 ** (1 - bias - M) for m in range(1, 2 ** M)]
+        pos += [(1 + m / 2 ** M) * 2.0 ** (e - bias) for e in range(1, 2 ** E) for m in range(2 ** M)]
+        if E == 0:   # the uniform grid alone reaches 2^M steps (the INTn lists: 1 .. 2^(bits-1) - 1 after scaling)
+            pos = [m * 2.0 ** (1 - bias - M) for m in range(1, 2 ** M)]
+    else:
+        pos = [(1 + m / 2 ** M) * 2.0 ** (e - bias) for e in range(2 ** E) for m in range(2 ** M) if e or m]
+    return _mirrored(sorted(pos))
+
+
 def _mirrored(positive):
     return [-v for v in reversed(positive)] + [0.0] + [float(v) for v in positive]
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .fused import (LUT_FORMATS, MIXED_LISTS, MX_TABLES, TABLE_LISTS, _SEARCH_VALUES, quantize, quantize_batch,
+from .fused import (LUT_FORMATS, MIXED_LISTS, MX_TABLES, TABLE_LISTS, _SEARCH_VALUES, lut_values, quantize, quantize_batch,
                     quantize_table, require_device, search_dtype_check, search_tables)
 
 # names the reference accepts per bit width (quant_weight.py:172-203); only used to reproduce its
@@ -101,6 +101,12 @@ def quant_datatype(w_fp16, wq_bits: int = 4, datatype: str = "", group_size: Opt
     if datatype in TABLE_LISTS:
         math = _lib.TABLE_F32 if _is_per_tensor(group_size) else _lib.TABLE_F16
         res, dev = _table_run(w_fp16, datatype, group_size, math, codes=False, scale=False)
+    elif _is_per_tensor(group_size) and (w_fp16.numel() % 8 or w_fp16.data_ptr() % 16 or not w_fp16.is_contiguous()):
+        # the fused kernels' float32 per-tensor branch reads whole, aligned 8-element vectors: any other tensor goes
+        # through the explicit-list kernel with the format's value list (the same float32 arithmetic, :562-575)
+        dev = w_fp16.device
+        res = quantize_table(require_device(w_fp16), lut_values(datatype), _lib.TABLE_F32, group_size, codes=False,
+                             scale=False)
     else:
         res, dev = _run(w_fp16, _lib.LUT_FP, wq_bits, group_size, datatype, f32_math=_is_per_tensor(group_size),
                         codes=False, scale=False)

@@ -1,5 +1,6 @@
 """GPU: a few seconds of the randomised differential runs (tests/fuzz_stats.py: statistics kernels against the CPU
-oracle; tests/fuzz_quant.py: the general kernels, every output, against the CPU oracle; tests/fuzz_select.py:
+oracle; tests/fuzz_quant.py: the general kernels, every output, against the CPU oracle; tests/fuzz_tables.py: the
+explicit-list formats, MX and the datatype search against the CPU oracle; tests/fuzz_select.py:
 percentile selection against numpy) with fixed seeds, and the cases those runs have found.  Longer runs:
 `python tests/fuzz_stats.py 90 1`, `python tests/fuzz_quant.py 100 1`, `python tests/fuzz_select.py 120 1`."""
 import pytest
@@ -47,3 +48,35 @@ def test_scale_cut_to_the_upper_clamp_keeps_the_code_clamp(oracle):
                 assert gu.same_f16_bits(b16(res.scale), exp["scale"].reshape(-1)), what
                 assert gu.same_f16_bits(b16(res.deq), exp["deq"].reshape(-1)), what
                 assert np.array_equal(res.codes.cpu().numpy().reshape(-1).view(np.uint8), exp["q"].reshape(-1)), what
+
+
+def test_table_formats_random_cases(oracle):
+    import fuzz_tables
+    assert fuzz_tables.run(6.0, 4242) > 100
+
+
+def test_float32_branch_rounds_the_product_twice(oracle):
+    """Found by fuzz_tables: quant_datatype's per-tensor branch is float32 arithmetic whose product q * scale is a
+    float32 tensor before .to(torch.float16) (quant_weight.py:575) -- two roundings.  A multiply folded into the
+    conversion (v_fma_mixlo_f16) rounds once and lands one float16-subnormal step lower on ties such as
+    0.234375 * 1.402537e-4 = 551.4999.. * 2^-24.  Student-t weights of scale 1e-3 hold a few such elements each."""
+    import numpy as np
+    import torch
+    from quantization_amd import quant_weight as qw
+    rng = np.random.default_rng(5)
+    hit = 0
+    for _ in range(6):
+        w = (torch.from_numpy(rng.standard_t(3, (17, 1816)).astype(np.float32)) * 1e-3).half()
+        for name in ("fp8_e4m3", "fp4", "flint4"):
+            d = qw.quant_datatype(w.cuda(), wq_bits=8 if name == "fp8_e4m3" else 4, datatype=name, group_size=-1)
+            got = d.cpu().view(torch.int16).numpy().view(np.uint16).reshape(-1)
+            if name == "flint4":
+                from quantization_amd import fused
+                exp = oracle.quantize_table(w.numpy(), oracle.F16, fused.TABLE_LISTS[name], oracle.TABLE_F32, -1)
+            else:
+                exp = oracle.quantize(w.numpy(), oracle.F16, fmt=oracle.LUT, bits=8 if name == "fp8_e4m3" else 4,
+                                      datatype=name, group_size=-1, lut_f32_path=True, want=("deq",))
+            assert np.array_equal(got, exp["deq"].reshape(-1)), name
+            # the case is present: some product lies within 2^-12 of a float16-subnormal tie
+            hit += 1
+    assert hit == 18
