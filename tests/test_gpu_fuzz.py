@@ -1,7 +1,8 @@
 """GPU: a few seconds of the randomised differential runs (tests/fuzz_stats.py: statistics kernels against the CPU
 oracle; tests/fuzz_quant.py: the general kernels, every output, against the CPU oracle; tests/fuzz_tables.py: the
 explicit-list formats, MX and the datatype search against the CPU oracle; tests/fuzz_select.py:
-percentile selection against numpy) with fixed seeds, and the cases those runs have found.  Longer runs:
+percentile selection against numpy; tests/fuzz_errors.py: the error half against the scripts' numpy arithmetic;
+tests/fuzz_sweep.py: SweepPlan against model_records against layer_record) with fixed seeds, and the cases those runs have found.  Longer runs:
 `python tests/fuzz_stats.py 90 1`, `python tests/fuzz_quant.py 100 1`, `python tests/fuzz_select.py 120 1`."""
 import pytest
 
@@ -80,3 +81,13 @@ def test_float32_branch_rounds_the_product_twice(oracle):
             # the case is present: some product lies within 2^-12 of a float16-subnormal tie
             hit += 1
     assert hit == 18
+
+
+def test_error_half_random_cases(oracle):
+    import fuzz_errors
+    assert fuzz_errors.run(5.0, 99) > 100
+
+
+def test_model_sweep_random_cases():
+    import fuzz_sweep
+    assert fuzz_sweep.run(5.0, 31) > 50
