@@ -450,6 +450,53 @@ def gen_onnx():
     print("onnx/", meta)
 
 
+API_ERROR_CASES = [
+    # (function, positional / keyword arguments after the weight, weight shape)
+    ("quant_int", dict(wq_bits=8, group_size=48), (4, 128)),
+    ("quant_int", dict(wq_bits=8, group_size=32), (128,)),
+    ("quant_int", dict(wq_bits=8, group_size=None), (128,)),
+    ("quant_int", dict(wq_bits=8, group_size=-1), (128,)),
+    ("quant_int", dict(wq_bits=8, group_size=32), (2, 4, 64)),
+    ("quant_int_asym", dict(wq_bits=4, group_size=100), (4, 128)),
+    ("_int_quant_meta", dict(wq_bits=8, asym=True, group_size=48), (4, 128)),
+    ("_int_quant_meta", dict(wq_bits=8, asym=False, group_size=64), (128,)),
+    ("quant_datatype", dict(wq_bits=7, datatype="fp8_e4m3", group_size=None), (4, 128)),
+    ("quant_datatype", dict(wq_bits=8, datatype="nonsense", group_size=None), (4, 128)),
+    ("quant_datatype", dict(wq_bits=4, datatype="fp8_e4m3", group_size=None), (4, 128)),
+    ("quant_datatype", dict(wq_bits=8, datatype="fp8_e4m3", group_size=48), (4, 128)),
+    ("quant_datatype", dict(wq_bits=2, datatype="fp8_e5m2", group_size=None), (4, 128)),
+    ("_fp_quant_meta", dict(wq_bits=7, datatype="fp8_e4m3", group_size=None), (4, 128)),
+    ("_fp_quant_meta", dict(wq_bits=8, datatype="int8_asym", group_size=None), (4, 128)),
+    ("_fp_quant_meta", dict(wq_bits=8, datatype="fp8_e3m4", group_size=48), (4, 128)),
+    ("quant_mx", dict(wq_bits=5, datatype="mx_fp4", group_size=32), (4, 128)),
+    ("quant_mx", dict(wq_bits=4, datatype="mx_fp3", group_size=32), (4, 128)),
+    ("quant_mx", dict(wq_bits=4, datatype="mx_fp4", group_size=48), (4, 128)),
+    ("search_datatype", dict(wq_bits=5, datatype="mixed_er", group_size=None), (4, 128)),
+    ("search_datatype", dict(wq_bits=4, datatype="mixed_er", group_size=48), (4, 128)),
+]
+
+
+def gen_api_errors():
+    """What the reference raises (or returns) for arguments outside its domain: exception type and message per case,
+    or the result's dtype / shape when it goes through."""
+    out = []
+    for fn, kw, shape in API_ERROR_CASES:
+        torch.manual_seed(1)
+        w = (torch.randn(*shape) * 0.02).half()
+        entry = {"fn": fn, "kwargs": kw, "shape": list(shape)}
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = getattr(qw, fn)(w, **kw)
+            r0 = r[0] if isinstance(r, tuple) else r
+            entry["ok"] = {"dtype": str(r0.dtype), "shape": list(r0.shape)}
+        except Exception as e:   # noqa: BLE001 -- the point is to record whatever it raises
+            entry["raises"] = [type(e).__name__, str(e)]
+        out.append(entry)
+        print(fn, kw, shape, "->", entry.get("raises") or entry.get("ok"))
+    with open(os.path.join(HERE, "api_errors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 QUANT_MODEL_CASES = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp4", 4)]
 QUANT_MODEL_GROUPS = [None, 64, -1]
 
@@ -564,6 +611,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "specials":
         gen_specials()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "api":
+        gen_api_errors()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "onnx":
         gen_onnx()

@@ -292,6 +292,32 @@ def test_batched_launch_equals_single(qa):
                 assert torch.equal(rb.seg_sse[i], r1.seg_sse) and torch.equal(rb.totals[i], r1.totals)
 
 
+def test_out_of_domain_arguments_behave_as_the_reference(qa):
+    """tests/golden/api_errors.json (gen_golden.py api): what the imported reference raises -- type and message --
+    or returns -- dtype and shape -- for bit widths, datatypes, group sizes and tensor ranks outside its domain."""
+    import json
+    import os
+    import torch
+    qw = qa.quant_weight
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_errors.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 20
+    for c in cases:
+        torch.manual_seed(1)
+        w = (torch.randn(*c["shape"]) * 0.02).half().cuda()
+        fn, what = getattr(qw, c["fn"]), (c["fn"], c["kwargs"], c["shape"])
+        if "raises" in c:
+            exc = {"RuntimeError": RuntimeError, "ValueError": ValueError, "AssertionError": AssertionError}[c["raises"][0]]
+            with pytest.raises(exc) as info:
+                fn(w, **c["kwargs"])
+            assert type(info.value) is exc, what
+            assert str(info.value) == c["raises"][1], what
+        else:
+            r = fn(w, **c["kwargs"])
+            r0 = r[0] if isinstance(r, tuple) else r
+            assert str(r0.dtype) == c["ok"]["dtype"] and list(r0.shape) == c["ok"]["shape"], what
+
+
 def test_fused_p99_matches_numpy_on_the_dump():
     """quantize_batch(p99=): the percentile selected inside the quantize pass equals np.percentile of the
     float32 |error| dump bit for bit, on shapes that take the fed route (team / wave / workgroup kernels,
