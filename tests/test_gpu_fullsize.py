@@ -103,3 +103,30 @@ def test_c2_sized_batch_heavy_tails(gs):
         for k in range(B):
             want = np.percentile(err[k].cpu().numpy().ravel(), pct)
             assert res.abs_p99[k].cpu().numpy().view(np.uint32) == want.view(np.uint32), (gs, pct, k)
+
+
+def test_tensor_beyond_the_32_bit_buffer_offsets():
+    """A 4.8 GB bfloat16 tensor: above the 0xf0000000-byte limit of the statistics kernels' buffer loads, so the
+    launcher takes the general kernels.  Additivity: scales equal, and list entries / totals within the 1e-6
+    contract of, the results over its two halves (each inside the limit, statistics kernels)."""
+    import torch
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rows, cols = 36864, 65536
+    w = torch.empty(rows, cols, dtype=torch.bfloat16, device="cuda")
+    for r in range(0, rows, 4096):
+        w[r:r + 4096] = (torch.randn(4096, cols, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    kw = dict(deq=False, codes=False, scale=True, seg_mse=True, totals=True)
+    for fmt, table, gs in ((_lib.INT_SYM, None, 128), (_lib.INT_ASYM, None, None), (_lib.LUT_FP, "fp8_e4m3", 64)):
+        whole = quantize(w, fmt, 8, gs, table, **kw)
+        a = quantize(w[: rows // 2], fmt, 8, gs, table, **kw)
+        b = quantize(w[rows // 2:], fmt, 8, gs, table, **kw)
+        tot = a.totals + b.totals
+        assert ((whole.totals - tot).abs() / tot).max().item() < 1e-6
+        assert torch.equal(whole.scale.view(torch.int16).reshape(-1),
+                           torch.cat([a.scale.reshape(-1), b.scale.reshape(-1)]).view(torch.int16))
+        assert torch.allclose(whole.seg_mse.reshape(-1), torch.cat([a.seg_mse.reshape(-1), b.seg_mse.reshape(-1)]),
+                              rtol=2e-6, atol=0)
+    del w
+    torch.cuda.empty_cache()
