@@ -146,6 +146,32 @@ int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype
                       const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /*
+ * One pass of a model sweep as ONE launch over tensors of DIFFERENT shapes (statistics only): the reference's loop
+ * over every nn.Linear of a model (quant_weight.py:660-704) with the error arithmetic of
+ * MSE&P99/quant_error_single_weight.py:46-79 fused in, for float16 / bfloat16 weights whose segments have one length:
+ * groups of 32 .. 512 elements (a power of two; any shapes whose column counts the group divides) or rows of 520 ..
+ * 32768 elements (per-channel: tensors with the same column count, any row counts).  Every item requests seg_sse and
+ * / or totals (and scale / zero_point if wanted) and none of deq / codes / abs_err.
+ *
+ * mq_sweep_prepare validates and writes the launch table -- mq_sweep_table_bytes(count) bytes, per tensor its
+ * pointers, segment count and range of workgroups (one workgroup per 128 KiB of weights) -- into HOST memory; the
+ * caller copies it to the device once (the weights and result buffers stay where they are between runs) and
+ * mq_sweep_run enqueues the pass: a one-dimensional grid of total_blocks workgroups, each finding its tensor in the
+ * table, then one launch that sums every tensor's per-workgroup partial sums in a fixed order.  workspace:
+ * mq_sweep_workspace_bytes(total_blocks) bytes.  Results are those of mq_quantize_batch on each tensor (per-segment
+ * values bit for bit; the float64 totals are summed over a different number of workgroups).
+ * MQ_ERR_UNSUPPORTED: a shape, dtype, alignment or configuration outside the above -- use mq_quantize_batch.
+ */
+size_t mq_sweep_table_bytes(int32_t count);
+size_t mq_sweep_workspace_bytes(int64_t total_blocks);
+int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows, const int64_t* cols, int32_t count,
+                     int32_t w_dtype, const mq_quant_cfg* cfg, void* table_host, size_t table_bytes,
+                     int64_t* seg_len, int64_t* total_blocks);
+int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
+                 const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
+                 void* hip_stream);
+
+/*
  * mq_quantize_batch plus p99[i] = np.percentile(abs_err_i, pct) (float32, method 'linear': the P99 of
  * elwise_error/onnx_error_cli.py:113-114) for every tensor, with the selection fed from the quantize pass
  * itself: a sampling pass over 1/32 of the weight brackets the wanted ranks, the full pass counts the errors

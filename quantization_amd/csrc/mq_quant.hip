@@ -80,7 +80,9 @@ struct QuantParams {
   double seg_mse_scale;  // 0: seg_sse receives float64 sums; 1 / L: seg_sse points to float32 words that receive
                          // the segment's mean squared error float32(sum * (1 / L))
   int32_t seg_exact;     // the float32 entry is summed in numpy's pairwise order instead (k_stats_group<.., true>)
-  double* partials;      // [gridDim.x][2]
+  double* partials;      // [gx][2]
+  uint32_t bx, gx;       // this workgroup's index among the gx workgroups that share the tensor (blockIdx.x and
+                         // gridDim.x, or the tensor's block range of a sweep launch)
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
   int32_t sel_mode;      // SEL_FEED_*: feed the float32 |error| values to a percentile selection
   SelWs* sel_ws;         // this tensor's selection workspace
@@ -109,8 +111,25 @@ struct BatchItem {
   double* seg_sse;
   double* totals;
 };
+// One pass over tensors of DIFFERENT sizes in one launch (statistics kernels): a one-dimensional grid, tensor i
+// owns the workgroups [blk0, blk0 + nblk) and has its own segment count; the table lives in device memory (any
+// number of tensors; the kernel arguments could not hold it).
+struct SweepItem {  // 64 bytes
+  const void* w;
+  uint16_t* scale;
+  uint16_t* zp;
+  double* seg_sse;
+  double* totals;
+  int64_t nseg;
+  uint32_t blk0, nblk;
+  int64_t pad;
+};
+static_assert(sizeof(SweepItem) == 64, "table entry");
 struct QuantBatch {
   QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
+  const SweepItem* sweep;  // non-null: a sweep launch (sweep_count entries sorted by blk0); item[] is unused
+  int32_t sweep_count;
+  double* sweep_partials;  // [total workgroups][2]
   int64_t ws_stride;   // bytes between the tensors' workspace slices
   char* sel_ws;        // selection workspace of tensor 0 (slices of sizeof(SelWs)), when common.sel_mode
   int64_t sample_stride;  // uint16 elements between the tensors' sample arrays (common.sel_samples: tensor 0)
@@ -120,6 +139,27 @@ static const size_t kWsHeader = 256;  // reduction words at the start of a tenso
 
 __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
   QuantParams p = b.common;
+  if (b.sweep) {
+    // the last entry whose first workgroup is not past this one (uniform over the workgroup: scalar loads)
+    int lo = 0, hi = b.sweep_count - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (b.sweep[mid].blk0 <= blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    const SweepItem& it = b.sweep[lo];
+    p.w = it.w; p.scale = it.scale; p.zp = it.zp; p.seg_sse = it.seg_sse;
+    p.deq = nullptr; p.codes = nullptr; p.abs_err = nullptr;
+    p.nseg = it.nseg;
+    p.n = it.nseg * p.L;
+    p.bx = blockIdx.x - it.blk0;
+    p.gx = it.nblk;
+    p.partials = b.sweep_partials + 2 * (int64_t)it.blk0;
+    p.tred = nullptr; p.sel_ws = nullptr; p.sel_samples = nullptr;
+    return p;
+  }
+  p.bx = blockIdx.x;
+  p.gx = gridDim.x;
   const BatchItem& it = b.item[blockIdx.y];
   p.w = it.w; p.deq = it.deq; p.codes = it.codes; p.scale = it.scale; p.zp = it.zp; p.abs_err = it.abs_err;
   p.seg_sse = it.seg_sse;
@@ -856,8 +896,8 @@ __device__ __forceinline__ void block_partials(const QuantParams& p, double sse,
   if (threadIdx.x == 0) {
     double a = 0, b = 0;
     for (int i = 0; i < nw; ++i) { a += lds[i]; b += lds[16 + i]; }
-    p.partials[2 * (int64_t)blockIdx.x] = a;
-    p.partials[2 * (int64_t)blockIdx.x + 1] = b;
+    p.partials[2 * (int64_t)p.bx] = a;
+    p.partials[2 * (int64_t)p.bx + 1] = b;
   }
 }
 
@@ -1364,7 +1404,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   __shared__ double lds[32];
   const int lane = threadIdx.x & 63, tl = lane & (T - 1), team = lane / T;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+  const int64_t gw = (int64_t)p.bx * 4 + wv, nwaves = (int64_t)p.gx * 4;
   const int64_t full = p.nseg / SPW, steps = (p.nseg + SPW - 1) / SPW;
   const char* wb = static_cast<const char*>(p.w);
   // A lane ends up holding the 64-byte run `lane` of the step's 4 KiB (four vectors of one segment; a team is T
@@ -1508,8 +1548,8 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k
   __shared__ double xs[2][4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t first = WPR == 1 ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x;
-  const int64_t stride = WPR == 1 ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x;
+  const int64_t first = WPR == 1 ? (int64_t)p.bx * 4 + wv : (int64_t)p.bx;
+  const int64_t stride = WPR == 1 ? (int64_t)p.gx * 4 : (int64_t)p.gx;
   const int sub = WPR == 1 ? 0 : wv;  // which part of the row this wave holds
   const char* wb = static_cast<const char*>(p.w);
   const int64_t row_bytes = p.L * 2;
@@ -1863,6 +1903,25 @@ __global__ __launch_bounds__(256) void k_finalize_totals(const QuantBatch b, int
       if (b.common.seg_mse_scale != 0.0) reinterpret_cast<float*>(it.seg_sse)[0] = (float)(x * b.common.seg_mse_scale);
       else it.seg_sse[0] = x;
     }
+  }
+}
+
+// The same for a sweep launch: one workgroup per table entry sums that tensor's block range.
+__global__ __launch_bounds__(256) void k_finalize_sweep(const QuantBatch b) {
+  __shared__ double lds[32];
+  const SweepItem& it = b.sweep[blockIdx.x];
+  const double* partials = b.sweep_partials + 2 * (int64_t)it.blk0;
+  double a = 0.0, c = 0.0;
+  for (uint32_t i = threadIdx.x; i < it.nblk; i += blockDim.x) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+  a = wave_sum(a);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) { lds[threadIdx.x >> 6] = a; lds[16 + (threadIdx.x >> 6)] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0 && it.totals) {
+    double x = 0.0, y = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { x += lds[i]; y += lds[16 + i]; }
+    it.totals[0] = x;
+    it.totals[1] = y;
   }
 }
 
@@ -2400,6 +2459,155 @@ extern "C" int mq_quantize_batch(const mq_quant_item* items, int32_t count, int3
     int rc = quantize_launch(items + done, c, w_dtype, rows, cols, cfg, workspace, st);
     if (rc) return rc;
   }
+  return MQ_OK;
+}
+
+// ---- one pass of a model sweep as ONE launch (tensors of different sizes) -------------------------------------
+// Which statistics kernel serves segments of L elements (the choice of quantize_launch for statistics-only calls on
+// float16 / bfloat16 weights), or false when none does.
+static bool sweep_scope(int64_t L, int* scope, int* nv, int* team_log2) {
+  if (L <= 0 || L % 8) return false;
+  const int64_t vecs = L / 8;
+  *team_log2 = 0;
+  if (vecs <= 64) {  // groups of 32 * 2^k elements
+    if (L % 32 || ((L / 32) & (L / 32 - 1))) return false;
+    *scope = SC_STATS_GROUP;
+    *team_log2 = ilog2_ceil(L / 32);
+    *nv = -4;
+  } else if (vecs <= 1024) {
+    *scope = SC_STATS_ROW;
+    *nv = vecs <= 128 ? 2 : vecs <= 256 ? 4 : vecs <= 512 ? 8 : vecs <= 768 ? 12 : 16;
+  } else if (vecs <= 4096) {
+    *scope = SC_STATS_ROWBLK;
+    *nv = vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
+  } else {
+    return false;
+  }
+  return true;
+}
+// Weight bytes one workgroup of a sweep launch works through.  Measured on the Llama-3-8B sweep (15 GB per pass):
+// 64 KiB 11.65 ms per four passes, 128 KiB 11.22, 256 KiB 11.23, 512 KiB 12.2 (the batched launches' grid cap
+// gives 235 KiB there: 11.42).  MQ_SWEEP_WG_KB overrides it for tuning runs.
+static int64_t sweep_wg_bytes() {
+  static const int64_t v = [] {
+    const char* e = getenv("MQ_SWEEP_WG_KB");
+    int64_t kb = e ? atoll(e) : 128;
+    return (kb < 4 ? 4 : (kb > 65536 ? 65536 : kb)) * 1024;
+  }();
+  return v;
+}
+static int sweep_check_cfg(int32_t w_dtype, const mq_quant_cfg* cfg) {
+  if (!cfg) return MQ_ERR_ARG;
+  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16) return w_dtype == MQ_F32 ? MQ_ERR_UNSUPPORTED : MQ_ERR_ARG;
+  const bool is_lut = cfg->format == MQ_LUT_FP || cfg->format == MQ_LUT_FP_SUB;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && !is_lut) return MQ_ERR_ARG;
+  if (!is_lut && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math || cfg->group_size == -1) return MQ_ERR_UNSUPPORTED;
+  if (cfg->format == MQ_LUT_FP && cfg->man_bits > 6) return MQ_ERR_UNSUPPORTED;
+  return MQ_OK;
+}
+
+extern "C" size_t mq_sweep_table_bytes(int32_t count) { return (size_t)(count < 1 ? 1 : count) * sizeof(SweepItem); }
+extern "C" size_t mq_sweep_workspace_bytes(int64_t total_blocks) {
+  return (size_t)(total_blocks < 1 ? 1 : total_blocks) * 2 * sizeof(double);
+}
+
+extern "C" int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows, const int64_t* cols, int32_t count,
+                                int32_t w_dtype, const mq_quant_cfg* cfg, void* table_host, size_t table_bytes,
+                                int64_t* seg_len, int64_t* total_blocks) {
+  if (!items || !rows || !cols || count < 1 || !table_host || !seg_len || !total_blocks) return MQ_ERR_ARG;
+  if (int rc = sweep_check_cfg(w_dtype, cfg)) return rc;
+  if (table_bytes < mq_sweep_table_bytes(count)) return MQ_ERR_WORKSPACE;
+  const int64_t L = cfg->group_size > 0 ? cfg->group_size : cols[0];
+  int scope, nv, team_log2;
+  if (!sweep_scope(L, &scope, &nv, &team_log2)) return MQ_ERR_UNSUPPORTED;
+  const mq_quant_out& o0 = items[0].out;
+  if (o0.seg_mse_f32 < 0 || o0.seg_mse_f32 > 2) return MQ_ERR_ARG;
+  if (o0.seg_mse_f32 == 2 && !(o0.seg_sse && scope == SC_STATS_GROUP && team_log2 <= 2)) return MQ_ERR_UNSUPPORTED;
+  if (!o0.seg_sse && !o0.totals) return MQ_ERR_ARG;  // nothing to compute
+  // workgroups per tensor: one per sweep_wg_bytes() of weights, in whole steps of the kernel
+  int64_t unit_bytes, units_per_block;  // a unit = what one wave (one workgroup: SC_STATS_ROWBLK) takes per step
+  if (scope == SC_STATS_GROUP) unit_bytes = 4096;
+  else unit_bytes = L * 2;
+  units_per_block = sweep_wg_bytes() / unit_bytes / (scope == SC_STATS_ROWBLK ? 1 : 4);
+  if (units_per_block < 1) units_per_block = 1;
+  if (scope != SC_STATS_ROWBLK) units_per_block *= 4;
+  SweepItem* t = static_cast<SweepItem*>(table_host);
+  int64_t blocks = 0;
+  for (int32_t i = 0; i < count; ++i) {
+    const mq_quant_out& o = items[i].out;
+    if (rows[i] < 1 || cols[i] < 1 || !items[i].w) return MQ_ERR_ARG;
+    if (cfg->group_size > 0 ? cols[i] % L != 0 : cols[i] != L) return cfg->group_size > 0 ? MQ_ERR_GROUP : MQ_ERR_ARG;
+    if (o.deq || o.codes || o.abs_err) return MQ_ERR_UNSUPPORTED;  // statistics only
+    if (!o.seg_sse != !o0.seg_sse || !o.totals != !o0.totals || !o.scale != !o0.scale ||
+        !o.zero_point != !o0.zero_point || o.seg_mse_f32 != o0.seg_mse_f32)
+      return MQ_ERR_ARG;
+    if (!aligned(items[i].w, 16)) return MQ_ERR_UNSUPPORTED;  // (the batched entry points take unaligned weights)
+    if (!aligned(o.scale, 2) || !aligned(o.zero_point, 2) || !aligned(o.seg_sse, o.seg_mse_f32 ? 4 : 8) ||
+        !aligned(o.totals, 8))
+      return MQ_ERR_ALIGN;
+    const int64_t n = rows[i] * cols[i];
+    if (n * 2 > 0xf0000000ll) return MQ_ERR_UNSUPPORTED;  // the 32-bit offsets of the buffer loads
+    const int64_t nseg = n / L;
+    const int64_t units = scope == SC_STATS_GROUP ? (nseg + (64 >> team_log2) - 1) / (64 >> team_log2) : nseg;
+    int64_t nb = (units + units_per_block - 1) / units_per_block;
+    if (nb < 1) nb = 1;
+    if (blocks + nb > 0x7fffffffll) return MQ_ERR_TOO_LARGE;
+    t[i] = SweepItem{items[i].w, static_cast<uint16_t*>(o.scale), static_cast<uint16_t*>(o.zero_point), o.seg_sse,
+                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, 0};
+    blocks += nb;
+  }
+  *seg_len = L;
+  *total_blocks = blocks;
+  return MQ_OK;
+}
+
+extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
+                            const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
+                            void* hip_stream) {
+  if (!table_dev || count < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll) return MQ_ERR_ARG;
+  if (int rc = sweep_check_cfg(w_dtype, cfg)) return rc;
+  if (seg_mse_f32 < 0 || seg_mse_f32 > 2) return MQ_ERR_ARG;
+  int scope, nv, team_log2;
+  if (!sweep_scope(seg_len, &scope, &nv, &team_log2)) return MQ_ERR_UNSUPPORTED;
+  if (seg_mse_f32 == 2 && !(scope == SC_STATS_GROUP && team_log2 <= 2)) return MQ_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < mq_sweep_workspace_bytes(total_blocks)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 16) || !aligned(table_dev, 16)) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  QuantBatch b = {};
+  QuantParams& p = b.common;
+  p.in_dtype = w_dtype;
+  p.L = seg_len;
+  p.vecs_per_seg = (int32_t)(seg_len / 8);
+  const int fmt = cfg->format;
+  if (fmt == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
+  else if (fmt == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
+  else if (!lut_consts(cfg, false, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
+  p.rqmax = 1.0f / p.qmax;
+  p.qmax_recip_ok = recip_ok_cached(p.qmax);
+  p.need_err = 1;
+  p.seg_mse_scale = seg_mse_f32 ? 1.0 / (double)seg_len : 0.0;
+  p.seg_exact = seg_mse_f32 == 2 ? 1 : 0;
+  p.sel_mode = SEL_FEED_OFF;
+  b.sweep = static_cast<const SweepItem*>(table_dev);
+  b.sweep_count = count;
+  b.sweep_partials = static_cast<double*>(workspace);
+  hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+  if (prof_on) {
+    if (int rc = prof_next_pair(&prof_e0, &prof_e1)) return rc;
+    MQ_HIP(hipEventRecord(prof_e0, st));
+  }
+  const dim3 grid((unsigned)total_blocks);
+  switch (fmt) {
+    case MQ_INT_SYM: mq_launch_fmt1(SEL_STATS_ONLY, scope, nv, 256, team_log2, grid, 0, st, b); break;
+    case MQ_INT_ASYM: mq_launch_fmt2(SEL_STATS_ONLY, scope, nv, 256, team_log2, grid, 0, st, b); break;
+    case MQ_LUT_FP: mq_launch_fmt3(SEL_STATS_ONLY, scope, nv, 256, team_log2, grid, 0, st, b); break;
+    default: mq_launch_fmt4(SEL_STATS_ONLY, scope, nv, 256, team_log2, grid, 0, st, b); break;
+  }
+  MQ_HIP(hipGetLastError());
+  if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
+  hipLaunchKernelGGL(k_finalize_sweep, dim3((unsigned)count), dim3(256), 0, st, b);
+  MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 

@@ -223,6 +223,16 @@ def bind_batch():
         L_.mq_quantize_p99_batch.argtypes = [ctypes.POINTER(_QuantItem), ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+        L_.mq_sweep_table_bytes.restype = sz
+        L_.mq_sweep_table_bytes.argtypes = [i32]
+        L_.mq_sweep_workspace_bytes.restype = sz
+        L_.mq_sweep_workspace_bytes.argtypes = [i64]
+        L_.mq_sweep_prepare.restype = ctypes.c_int
+        L_.mq_sweep_prepare.argtypes = [ctypes.POINTER(_QuantItem), ctypes.POINTER(i64), ctypes.POINTER(i64), i32, i32,
+                                        ctypes.POINTER(_lib.QuantCfg), vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+        L_.mq_sweep_run.restype = ctypes.c_int
+        L_.mq_sweep_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), i32, vp, sz, vp]
         L_._batch_bound = True
     return L_
 

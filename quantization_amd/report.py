@@ -194,14 +194,17 @@ class SweepPlan:
     0).  lists(k) -> the float32 per-vector MSE lists of pass k, in the order of `weights`.  Records and lists live in
     buffers of the plan: the next run() overwrites them.
 
-    Per pass the layers are grouped by (shape, dtype), one fused launch per 32 of them (mq_quantize_batch,
-    statistics only, float32 MSE lists).  The selections of pass k -- chains of short launches that leave most of
+    Per pass ONE fused launch takes every layer whose segments have one length, whatever the shapes (mq_sweep_run:
+    per-group passes the whole model, per-channel passes the layers of one column count; statistics only, float32
+    MSE lists); layers the sweep form does not take go in batches of 32 same-shaped ones (mq_quantize_batch;
+    single_launch=False: everything does).  The selections of pass k -- chains of short launches that leave most of
     the chip idle -- run on a second HIP stream while the current stream already streams the weights for pass
     k + 1; the streams are joined before run() returns, so the result is ordered on the current stream.
     numpy_order: as for model_records (every pass must then be per-group with 32 / 64 / 128 elements)."""
 
-    def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False):
+    def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True):
         import ctypes
+        import os
         from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
         self.weights = list(weights)
         self.passes = list(passes)
@@ -214,9 +217,9 @@ class SweepPlan:
             if w.dim() != 2 or not w.is_cuda or w.device != dev or w.dtype not in _DTYPES or not w.is_contiguous():
                 raise ValueError("SweepPlan takes contiguous 2-D float16 / bfloat16 / float32 ROCm weights on one device")
             groups.setdefault((tuple(w.shape), w.dtype), []).append(i)
-        self.order = [i for idx in groups.values() for i in idx]           # launch order -> index into weights
+        self.order = [i for idx in groups.values() for i in idx]           # row of the tables -> index into weights
         nl = len(self.order)
-        self.L = bind_batch()
+        self.L = L = bind_batch()
         from . import error_metrics
         error_metrics._bind()
         self.numel = torch.tensor([float(self.weights[i].numel()) for i in self.order], dtype=torch.float64, device=dev)
@@ -224,41 +227,79 @@ class SweepPlan:
         self.records = torch.zeros(len(self.passes), nl, len(RECORD_FIELDS), dtype=torch.float64, device=dev)
         self.ws_bytes = 0
         self.plan = []
+        if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
+            single_launch = False
         for datatype, bits, group_size in self.passes:
             fmt, table = format_code(datatype)
             if table in TABLE_LISTS:
                 raise ValueError("SweepPlan: the explicit-list tables go layer by layer (model_records)")
             cfg = make_cfg(fmt, bits, group_size, table)
+            gs = cfg.group_size
             totals = torch.zeros(nl, 2, dtype=torch.float64, device=dev)
             p99 = torch.zeros(nl, dtype=torch.float64, device=dev)
-            launches, lists, ptrs, ns, row = [], [None] * len(self.weights), [], [], 0
-            for (shape, dtype), idx in groups.items():
-                K, C = shape
-                gs = cfg.group_size
+            # the per-vector MSE lists of the pass: one float32 buffer, every list 32-byte aligned
+            ns, offs, total = [], [], 0
+            for i in self.order:
+                K, C = self.weights[i].shape
                 Lseg = K * C if gs == -1 else (C if gs <= 0 else gs)
                 if gs > 0 and C % gs:
                     raise RuntimeError(f"shape '[{K}, {C // gs}, {gs}]' is invalid for input of size {K * C}")
-                nseg = K * C // Lseg
-                nseg_pad = (nseg + 7) // 8 * 8
-                for lo in range(0, len(idx), 32):
-                    sel = idx[lo:lo + 32]
-                    B = len(sel)
-                    mse = torch.empty(B, nseg_pad, dtype=torch.float32, device=dev)
-                    items = (_QuantItem * B)()
-                    for j, i in enumerate(sel):
-                        items[j].w = self.weights[i].data_ptr()
-                        o = items[j].out
-                        o.abs_err_dtype = _lib.F32
-                        o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
-                        o.seg_sse = mse.data_ptr() + j * nseg_pad * 4
-                        o.totals = totals.data_ptr() + (row + j) * 16
-                        lists[i] = mse[j, :nseg]
-                        ptrs.append(o.seg_sse)
-                        ns.append(nseg)
-                    self.ws_bytes = max(self.ws_bytes, self.L.mq_quantize_batch_workspace_bytes(B, K, C, ctypes.byref(cfg)))
-                    launches.append((items, B, _DTYPES[dtype], K, C, mse))
-                    row += B
-            self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists,
+                ns.append(K * C // Lseg)
+                offs.append(total)
+                total += (ns[-1] + 7) // 8 * 8
+            mse = torch.empty(total, dtype=torch.float32, device=dev)
+            lists = [None] * len(self.weights)
+            for pos, i in enumerate(self.order):
+                lists[i] = mse[offs[pos]:offs[pos] + ns[pos]]
+            ptrs = [mse.data_ptr() + o * 4 for o in offs]
+
+            def make_items(poss):
+                items = (_QuantItem * len(poss))()
+                for j, pos in enumerate(poss):
+                    items[j].w = self.weights[self.order[pos]].data_ptr()
+                    o = items[j].out
+                    o.abs_err_dtype = _lib.F32
+                    o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
+                    o.seg_sse = ptrs[pos]
+                    o.totals = totals.data_ptr() + pos * 16
+                return items
+
+            # Launches.  Layers whose segments have one length go through ONE launch whatever their shapes (the
+            # library's sweep form: per-group passes take the whole model, per-channel passes the layers of one
+            # column count); what it does not take -- float32 weights, per-tensor passes, other group sizes --
+            # goes in batches of up to 32 same-shaped layers.
+            launches = []
+            keys: Dict[Tuple, List[int]] = {}
+            for pos, i in enumerate(self.order):
+                w = self.weights[i]
+                keys.setdefault((w.dtype, w.shape[1] if gs <= 0 else None), []).append(pos)
+            for (dtype, _), poss in keys.items():
+                if single_launch and gs != -1:
+                    items = make_items(poss)
+                    n = len(poss)
+                    rows = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[0] for pos in poss])
+                    cols = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[1] for pos in poss])
+                    host = torch.empty(L.mq_sweep_table_bytes(n), dtype=torch.uint8)
+                    seg_len, blocks = ctypes.c_int64(0), ctypes.c_int64(0)
+                    rc = L.mq_sweep_prepare(items, rows, cols, n, _DTYPES[dtype], ctypes.byref(cfg), host.data_ptr(),
+                                            host.numel(), ctypes.byref(seg_len), ctypes.byref(blocks))
+                    if rc == _lib.OK:
+                        launches.append(("sweep", host.to(dev), n, seg_len.value, blocks.value, _DTYPES[dtype],
+                                         2 if numpy_order else 1))
+                        self.ws_bytes = max(self.ws_bytes, L.mq_sweep_workspace_bytes(blocks.value))
+                        continue
+                    if rc != _lib.ERR_UNSUPPORTED:
+                        _lib.check(rc)
+                by_shape: Dict[Tuple, List[int]] = {}
+                for pos in poss:
+                    by_shape.setdefault(tuple(self.weights[self.order[pos]].shape), []).append(pos)
+                for (K, C), same in by_shape.items():
+                    for lo in range(0, len(same), 32):
+                        sel = same[lo:lo + 32]
+                        self.ws_bytes = max(self.ws_bytes,
+                                            L.mq_quantize_batch_workspace_bytes(len(sel), K, C, ctypes.byref(cfg)))
+                        launches.append(("batch", make_items(sel), len(sel), _DTYPES[dtype], K, C))
+            self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse,
                                   ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns)))
         self.sel_ws_bytes = self.L.mq_percentile_batch_workspace_bytes(min(nl, 64))
 
@@ -282,9 +323,15 @@ class SweepPlan:
             ws, _ = workspace(dev, self.ws_bytes)
             for k, ps in enumerate(self.plan):
                 cfg = ps["cfg"]
-                for items, B, dt, K, C, _ in ps["launches"]:
-                    _lib.check(L.mq_quantize_batch(items, B, dt, K, C, ctypes.byref(cfg), ws.data_ptr(), ws.numel(),
-                                                   main.cuda_stream))
+                for la in ps["launches"]:
+                    if la[0] == "sweep":
+                        _, tab, n, seg_len, blocks, dt, flag = la
+                        _lib.check(L.mq_sweep_run(tab.data_ptr(), n, seg_len, blocks, dt, ctypes.byref(cfg), flag,
+                                                  ws.data_ptr(), ws.numel(), main.cuda_stream))
+                    else:
+                        _, items, B, dt, K, C = la
+                        _lib.check(L.mq_quantize_batch(items, B, dt, K, C, ctypes.byref(cfg), ws.data_ptr(), ws.numel(),
+                                                       main.cuda_stream))
                 ready = torch.cuda.Event()
                 ready.record(main)
                 with torch.cuda.stream(side):

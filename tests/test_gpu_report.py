@@ -334,3 +334,54 @@ def test_model_sweep_equals_model_records():
             if k == 1:
                 assert all(torch.equal(a, b) for a, b in zip(vecs, wv))
     torch.cuda.synchronize()
+
+
+def test_single_launch_sweep_equals_per_shape_batches():
+    """SweepPlan's one-launch form (mq_sweep_run: every layer of a pass in one grid, per-tensor block ranges) against
+    the batches of same-shaped layers (mq_quantize_batch): per-vector lists and P99s bit for bit, sums to float64
+    rounding.  Shapes: Llama-like and ragged rows, a tensor smaller than one workgroup's share, NaN / inf / one-sided
+    rows; float16 and bfloat16 mixed in one model; a float32 weight and a per-tensor pass (not taken by the sweep
+    form) ride along in the fallback."""
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(1024, 2048), (96, 2048), (3000, 2048), (512, 5632), (8, 2048), (640, 11264), (256, 1024), (33, 8192)]
+    ws = [(torch.randn(*s, generator=g, device="cuda") * 0.02) for s in shapes]
+    ws[2][5, 7] = float("nan")
+    ws[2][9, :64] = float("inf")
+    ws[3][3] = ws[3][3].abs() + 0.01                     # a row on one side of zero
+    ws[5][1] *= 1e4                                      # scale cut by the clamp
+    mixed = [w.bfloat16() if i % 3 else w.half() for i, w in enumerate(ws)]
+    for weights in (mixed, [w.bfloat16() for w in ws], mixed[:3] + [ws[3].float()] + mixed[4:]):
+        passes = [("int8", 8, None), ("int8", 8, 32), ("int8_asym", 8, 64), ("fp8_e4m3", 8, 128), ("fp4", 4, 256),
+                  ("int8_asym", 8, None), ("fp8_e3m4", 8, None), ("int4", 4, 512), ("int8", 8, -1), ("int8", 8, 16)]
+        one = report.SweepPlan(weights, passes)
+        per = report.SweepPlan(weights, passes, single_launch=False)
+        kinds = [{la[0] for la in ps["launches"]} for ps in one.plan]
+        assert all(k == {"batch"} for k in ([{la[0] for la in ps["launches"]} for ps in per.plan]))
+        if all(w.dtype != torch.float32 for w in weights):
+            assert all(k == {"sweep"} for k in kinds[:8]) and kinds[8] == {"batch"} and kinds[9] == {"batch"}
+            # per-group passes: one launch per dtype; per-channel passes: one per (dtype, column count)
+            assert len(one.plan[1]["launches"]) == len({w.dtype for w in weights})
+        for _ in range(2):
+            a, b = one.run().clone(), per.run().clone()
+            torch.cuda.synchronize()
+            for k in range(len(passes)):
+                for la, lb in zip(one.lists(k), per.lists(k)):
+                    assert torch.equal(la.view(torch.int32), lb.view(torch.int32)), passes[k]
+                # numel, mse_p99: bit for bit; sums over a different number of workgroups: float64 rounding
+                for col in (0, 4, 5):
+                    assert torch.equal(a[k][:, col].view(torch.int64), b[k][:, col].view(torch.int64)), (passes[k], col)
+                for col in (1, 2, 3):
+                    x, y = a[k][:, col], b[k][:, col]
+                    same = (x == y) | (x.isnan() & y.isnan()) | ((x - y).abs() <= 1e-13 * y.abs())
+                    assert bool(same.all()), (passes[k], col)
+    # numpy-order entries through the sweep form
+    bf = [w.bfloat16() for w in ws]
+    for gs in (32, 64, 128):
+        one = report.SweepPlan(bf, [("int8", 8, gs)], numpy_order=True)
+        per = report.SweepPlan(bf, [("int8", 8, gs)], numpy_order=True, single_launch=False)
+        assert one.plan[0]["launches"][0][0] == "sweep"
+        a, b = one.run().clone(), per.run().clone()
+        assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(one.lists(0), per.lists(0)))
+        assert torch.equal(a[0][:, 4].view(torch.int64), b[0][:, 4].view(torch.int64))
+    torch.cuda.synchronize()
