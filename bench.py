@@ -7,8 +7,8 @@
 Headline workload "llama8b" (BASELINE.json configs[3]): all 225 linear weights of Llama-3-8B (random-init bf16,
 15.0 GB), symmetric int8 error statistics per-channel and per-group g = 32 / 64 / 128 -- four passes over the
 model per step -- with the layers SHARDED over the N ranks (greedy longest-processing-time on the element
-count; no weight crosses GPUs).  Per rank a pass is one fused launch per group of same-shaped layers
-(report.model_records); per step RCCL carries one all-reduce of the per-layer record table
+count; no weight crosses GPUs).  Per rank a pass is ONE fused launch over all its layers whose segments have one
+length (report.SweepPlan: mq_sweep_run; five launches per step); per step RCCL carries one all-reduce of the per-layer record table
 (distributed.gather_records) and the histogram all-reduces of one model-wide P99 taken jointly over every
 rank's per-channel MSE lists (distributed.joint_percentile).  "llama70b" (configs[4]) is the same over the 561
 weights of Llama-3-70B (139 GB) with int8 sym / asym, fp8_e4m3, fp8_e3m4 x {per-channel, g = 32 / 64 / 128};
@@ -148,7 +148,9 @@ class ModelSweep:
                      f"{dist_name} scale 0.02), int8 per-channel error statistics")
         self.desc += (" (per-layer tensor MSE, mean and exact P99 of the per-vector MSE list; one model-wide P99 over all "
                       f"layers' per-channel lists), layers sharded over {world} rank(s) by longest-processing-time")
-        self.kernel_desc = "statistics-only fused quantize pass (k_stats_row / k_stats_group: one launch per group of same-shaped layers)"
+        self.kernel_desc = ("statistics-only fused quantize pass (k_stats_row / k_stats_group: ONE launch per pass over all of the "
+                            "rank's layers whose segments have one length -- per-group passes the whole shard, per-channel passes "
+                            "the layers of one column count)")
 
     def step(self):
         import torch

@@ -5,8 +5,9 @@
  * Every function enqueues on the caller's stream and returns without synchronising unless it says
  * otherwise.  All buffers are allocated by the caller and the library keeps no pointer to them past the call.
  * State the library does keep: per calling thread, the last HIP error text, the event pool of the
- * mq_profile_* hook and a small cache of verified reciprocal constants; per process, the grid cap read once
- * from the environment variable MQ_MAX_BLOCKS (tuning runs) and, per device, the address of the static scratch
+ * mq_profile_* hook and a small cache of verified reciprocal constants; per process, the grid cap and the
+ * workgroup grain of the sweep launches, read once from the environment variables MQ_MAX_BLOCKS and
+ * MQ_SWEEP_WG_KB (tuning runs) and, per device, the address of the static scratch
  * array of mq_error_stats_static.  Functions return MQ_OK (0) or a negative mq_status and never throw.
  *
  * "Reference" citations are into /root/reference (weirdmaverick/quantization).
