@@ -162,12 +162,15 @@ class ModelSweep:
             # the per-channel lists of the first format feed the model-wide percentile
             if self.plan is None:
                 self.plan = SweepPlan(self.weights, self.passes)
-            local = self.plan.run(overlap=self.overlap).reshape(-1, len(RECORD_FIELDS))
+            self.plan.launch(overlap=self.overlap)
             vecs = self.plan.lists(self.joint_pass)
-        # RCCL: one all-reduce of the zero-filled record table of the whole sweep ...
-        table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
-        # ... and the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists
+        # RCCL: the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists -- enqueued
+        # behind the last quantize launch, beside the last pass's per-layer selections on the second stream ...
         model_p99 = joint_percentile(vecs, 99.0, dtype=torch.float32, total=self.total_vectors, wide=True)
+        if self.weights:
+            local = self.plan.finish().reshape(-1, len(RECORD_FIELDS))
+        # ... and one all-reduce of the zero-filled record table of the whole sweep
+        table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
         return table, model_p99
 
 

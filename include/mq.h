@@ -171,6 +171,14 @@ int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows, const int6
 int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
                  const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
+/*
+ * The report rows of one pass (the CSV rows of quant_error_multi_weight.py:142-151 before formatting): for tensor i
+ * of `count`, records[perm[i]][0..5] = numel[i], totals[i][0] (sum of squared errors), totals[i][1] (sum of |error|),
+ * totals[i][0] / numel[i] (mse_tensor = mse_rep, IEEE float64 division), p99[i] (mse_p99; NaN when the mean is NaN,
+ * as np.percentile of a list holding a NaN), 0.  All arrays are device arrays; one small launch.
+ */
+int mq_sweep_records(const double* totals, const double* p99, const double* numel, const int64_t* perm, int32_t count,
+                     double* records, void* hip_stream);
 
 /*
  * mq_quantize_batch plus p99[i] = np.percentile(abs_err_i, pct) (float32, method 'linear': the P99 of

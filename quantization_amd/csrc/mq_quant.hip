@@ -1925,6 +1925,22 @@ __global__ __launch_bounds__(256) void k_finalize_sweep(const QuantBatch b) {
   }
 }
 
+// The record rows of one pass of a sweep (numel, sse, sum |err|, mean squared error, P99 of the per-vector list, 0),
+// scattered into the order of the caller's weights: row perm[i] from the i-th tensor's totals and percentile.
+__global__ __launch_bounds__(256) void k_sweep_records(const double* totals, const double* p99, const double* numel,
+                                                       const int64_t* perm, int n, double* records) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double sse = totals[2 * i], mse = sse / numel[i];
+  double* r = records + 6 * perm[i];
+  r[0] = numel[i];
+  r[1] = sse;
+  r[2] = totals[2 * i + 1];
+  r[3] = mse;
+  r[4] = mse != mse ? mse : p99[i];  // a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
+  r[5] = 0.0;
+}
+
 #endif  // MQ_PART == 0
 
 // ================================================================================================
@@ -2607,6 +2623,18 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
   MQ_HIP(hipGetLastError());
   if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
   hipLaunchKernelGGL(k_finalize_sweep, dim3((unsigned)count), dim3(256), 0, st, b);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+extern "C" int mq_sweep_records(const double* totals, const double* p99, const double* numel, const int64_t* perm,
+                                int32_t count, double* records, void* hip_stream) {
+  if (count < 0 || (count > 0 && (!totals || !p99 || !numel || !perm || !records))) return MQ_ERR_ARG;
+  if (count == 0) return MQ_OK;
+  if (!aligned(totals, 8) || !aligned(p99, 8) || !aligned(numel, 8) || !aligned(perm, 8) || !aligned(records, 8))
+    return MQ_ERR_ALIGN;
+  hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), totals, p99, numel, perm, (int)count, records);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }

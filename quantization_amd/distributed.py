@@ -135,10 +135,18 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     out = torch.empty((), dtype=torch.float64 if wide else dtype, device=dev)
     _lib.check(L.mq_select_begin(wp, wn, st))
     levels = 1 if dtype == torch.float32 else 3
-    ptrs = (ctypes.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
-    lens = (ctypes.c_int64 * len(xs))(*[x.numel() for x in xs])
+    # lists that follow each other in memory without a gap (the per-channel lists of a SweepPlan pass live in one
+    # buffer) are histogrammed as one array: a launch takes 64 arrays, a model has hundreds of lists
+    runs = []
+    for x in xs:
+        if runs and runs[-1][0] + runs[-1][1] * x.element_size() == x.data_ptr():
+            runs[-1][1] += x.numel()
+        else:
+            runs.append([x.data_ptr(), x.numel()])
+    ptrs = (ctypes.c_void_p * len(runs))(*[r[0] for r in runs])
+    lens = (ctypes.c_int64 * len(runs))(*[r[1] for r in runs])
     for level in range(levels + 1):
-        _lib.check(L.mq_select_accumulate_multi(ptrs, lens, len(xs), code, level, wp, wn, st))
+        _lib.check(L.mq_select_accumulate_multi(ptrs, lens, len(runs), code, level, wp, wn, st))
         if dist_on:
             off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
             L.mq_select_layout(level, ctypes.byref(off), ctypes.byref(cnt))

@@ -310,6 +310,16 @@ class SweepPlan:
     def run(self, overlap: bool = True) -> torch.Tensor:
         """overlap=False keeps everything on the current stream (the selections of a pass then run between the
         passes, alone on the chip): for measurements of the quantize launches by themselves."""
+        self.launch(overlap)
+        return self.finish()
+
+    @torch.no_grad()
+    def launch(self, overlap: bool = True) -> None:
+        """run() without its last step: every pass is enqueued -- the quantize launches on the current stream, each
+        pass's selections and record rows on the second one -- but the current stream does not wait for the second
+        one yet.  What the caller enqueues on the current stream before finish() (a model-wide percentile over
+        lists(k), a collective) runs beside the last pass's selections: the lists are complete there, the records
+        and per-layer percentiles are not."""
         import ctypes
         from .fused import workspace
         dev, L = self.dev, self.L
@@ -340,12 +350,18 @@ class SweepPlan:
                     _lib.check(L.mq_percentile_multi(ps["ptrs"], ps["ns"], nl, _lib.F32_AS_F64, self.pct,
                                                      ps["p99"].data_ptr(), None, sws.data_ptr(), sws.numel(),
                                                      side.cuda_stream))
-                    tot = ps["totals"]
-                    mse = tot[:, 0] / self.numel
-                    # a list that holds a NaN has a NaN mean; np.percentile of it is NaN too
-                    p99 = torch.where(torch.isnan(mse), mse, ps["p99"])
-                    rec = torch.stack([self.numel, tot[:, 0], tot[:, 1], mse, p99, torch.zeros_like(mse)], dim=1)
-                    self.records[k].index_copy_(0, self.perm, rec)
+                    # the pass's rows of the record table (one launch: mean = sse / numel, NaN lists, row order)
+                    _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
+                                                  self.perm.data_ptr(), nl, self.records[k].data_ptr(),
+                                                  side.cuda_stream))
+            self._pending = (main, side)
+
+    @torch.no_grad()
+    def finish(self) -> torch.Tensor:
+        """Joins the second stream into the one launch() ran on and returns the records (ordered on that stream)."""
+        main, side = self._pending
+        self._pending = None
+        if side is not main:
             main.wait_stream(side)
         return self.records
 

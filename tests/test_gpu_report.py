@@ -178,15 +178,25 @@ def _sweep_worker(rank, world, port, backend, q):
     nl, width = len(ws), len(RECORD_FIELDS)
     index = torch.as_tensor([p * nl + i for p in range(len(SWEEP_PASSES)) for i in mine], device=dev)
     total = sum(w.shape[0] for w in ws)
-    for _ in range(3):
-        local = plan.run().reshape(-1, width)
+    seen = []
+    for it in range(4):
+        if it % 2 == 0:   # the whole sweep, then the model-wide percentile
+            local = plan.run().reshape(-1, width)
+            p99 = joint_percentile(plan.lists(0), 99.0, dtype=torch.float32, total=total, wide=True)
+        else:             # bench.py's order: the percentile (and its collectives) beside the last pass's selections
+            plan.launch()
+            p99 = joint_percentile(plan.lists(0), 99.0, dtype=torch.float32, total=total, wide=True)
+            local = plan.finish().reshape(-1, width)
         if world > 1:
             table = gather_records(index, local, nl * len(SWEEP_PASSES), width, dev)
         else:   # one rank: the collective itself, enqueued behind the two-stream sweep
             table = torch.zeros(nl * len(SWEEP_PASSES), width, dtype=torch.float64, device=dev)
             table[index] = local
             dist.all_reduce(table)
-        p99 = joint_percentile(plan.lists(0), 99.0, dtype=torch.float32, total=total, wide=True)
+        seen.append((table.clone(), p99.clone()))
+    torch.cuda.synchronize()
+    for t, p in seen[1:]:
+        assert torch.equal(t.view(torch.int64), seen[0][0].view(torch.int64)) and torch.equal(p, seen[0][1])
     q.put((rank, table.cpu().numpy(), float(p99)))
     dist.barrier()
     dist.destroy_process_group()
