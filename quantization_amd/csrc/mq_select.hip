@@ -60,6 +60,7 @@ __device__ __forceinline__ uint64_t key_of(double v) { return __builtin_bit_cast
 __device__ __forceinline__ void flush_top(const uint32_t* lh, uint32_t* fine, uint32_t* coarse) {
   for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) {
     const uint32_t c = lh[i];
+    if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;  // (most waves' 64 bins are empty: data spans few binades)
     if (c) atomicAdd(&fine[i], c);
     uint32_t sum = c;
 #pragma unroll
