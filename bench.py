@@ -492,7 +492,8 @@ def main():
                        "weight_bytes_per_step_whole_job": int(total_weight_bytes),
                        "gpu_ms_per_step_events_rank0": round(gpu_ms / args.steps, 4)},
             "roofline": roofline(local_algo, args.steps, kern_ms, kern_launches, wl.kernel_desc + " (rank 0)",
-                                 traffic_for(args.workload)),
+                                 # (the PMC passes measured the one-GPU launches: a shard's launches are smaller)
+                                 traffic_for(args.workload) if world == 1 else None),
         }
         if isolated:
             out["roofline"]["launch_alone"] = isolated
