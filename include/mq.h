@@ -150,8 +150,9 @@ int mq_quantize_batch(const mq_quant_item* items, int32_t count, int32_t w_dtype
  * One pass of a model sweep as ONE launch over tensors of DIFFERENT shapes (statistics only): the reference's loop
  * over every nn.Linear of a model (quant_weight.py:660-704) with the error arithmetic of
  * MSE&P99/quant_error_single_weight.py:46-79 fused in, for float16 / bfloat16 weights whose segments have one length:
- * groups of 32 .. 512 elements (a power of two; any shapes whose column counts the group divides) or rows of 520 ..
- * 32768 elements (per-channel: tensors with the same column count, any row counts).  Every item requests seg_sse and
+ * groups of 32 .. 512 elements (a power of two; any shapes whose column counts the group divides) or segments of 520
+ * .. 32768 elements, a multiple of 8 (per-channel: tensors with the same column count, any row counts; or longer
+ * groups).  Every item requests seg_sse and
  * / or totals (and scale / zero_point if wanted) and none of deq / codes / abs_err.
  *
  * mq_sweep_prepare validates and writes the launch table -- mq_sweep_table_bytes(count) bytes, per tensor its
