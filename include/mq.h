@@ -80,9 +80,12 @@ typedef struct {
                             receives each segment's mean squared error, float32(sum * (1 / length)): the list
                             entry compute_mse returns, a float32 np.mean (quant_error_single_weight.py:46-48),
                             to 1e-6; 2: the same array, each entry summed in float32 in the order of numpy's
-                            pairwise summation, so that it has the BITS of np.mean(diff * diff) -- statistics-only
-                            calls (no deq / codes / abs_err) on float16 / bfloat16 weights with groups of 32, 64
-                            or 128 elements; anything else returns MQ_ERR_UNSUPPORTED */
+                            summation (pairwise, in chunks of 8192 elements) and divided as np.mean divides, so
+                            that it has the BITS of np.mean(diff * diff) -- statistics-only calls (no deq / codes /
+                            abs_err) on 16-byte-aligned float16 / bfloat16 weights with segments (groups or rows)
+                            of a multiple of 8 and at most 32768 elements: groups of 32 / 64 / 128 elements in the
+                            bandwidth kernels, every other length in a wave-per-segment kernel that is several
+                            times slower; anything else returns MQ_ERR_UNSUPPORTED */
   double* seg_sse;       /* float64 [nseg] sum of squared float32 errors per segment (row form,
                             quant_error_single_weight.py:56-71 before the division by the length)  */
   double* totals;        /* float64 [2]: sum of squared errors, sum of absolute errors (float32 errors,

@@ -38,7 +38,7 @@
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3,
        // the statistics-only kernels (k_stats_*): groups of 32 * 2^team_log2 elements; rows held by one wave / by
        // a 256-thread workgroup with nv vectors per lane
-       SC_STATS_GROUP = 4, SC_STATS_ROW = 5, SC_STATS_ROWBLK = 6 };
+       SC_STATS_GROUP = 4, SC_STATS_ROW = 5, SC_STATS_ROWBLK = 6, SC_STATS_ROWNP = 7 };
 // The kernels' SEL template parameter: one of the SEL_FEED_* values, or SEL_STATS_ONLY = no selection feed and no
 // element-sized output (deq / codes / abs_err all absent: the sweeps that only want the error statistics), which
 // drops the per-vector tests of the output pointers and everything that only served the stores.
@@ -125,8 +125,21 @@ struct SweepItem {  // 64 bytes
   int64_t pad;
 };
 static_assert(sizeof(SweepItem) == 64, "table entry");
+// numpy's summation of a contiguous run of n float32 values (n a multiple of 8, n <= 32768), unrolled by the host:
+// chunks of 8192 elements (the reduction's inner loop size) added up in order, each chunk summed pairwise -- runs
+// longer than 128 elements are split in two, the left part n / 2 rounded down to a multiple of 8, until the parts
+// hold at most 128 elements (numpy/_core/src/umath/loops_utils.h.src).  len[i]: vectors (8 elements)
+// of leaf i, in memory order; ops: the post-order walk of the split tree, one bit per step -- 0: take the next
+// leaf's sum, 1: add the two newest partial sums (the older one on the left).
+#define MQ_NP_MAX_LEAVES 512
+struct NumpyProg {
+  uint16_t nleaves, nops;
+  uint8_t len[MQ_NP_MAX_LEAVES];
+  uint32_t ops[2 * MQ_NP_MAX_LEAVES / 32];
+};
 struct QuantBatch {
   QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
+  NumpyProg np;        // SC_STATS_ROWNP only
   const SweepItem* sweep;  // non-null: a sweep launch (sweep_count entries sorted by blk0); item[] is unused
   int32_t sweep_count;
   double* sweep_partials;  // [total workgroups][2]
@@ -135,6 +148,7 @@ struct QuantBatch {
   int64_t sample_stride;  // uint16 elements between the tensors' sample arrays (common.sel_samples: tensor 0)
   BatchItem item[MQ_MAX_BATCH];
 };
+static_assert(sizeof(QuantBatch) <= 4096, "kernel arguments");
 static const size_t kWsHeader = 256;  // reduction words at the start of a tensor's workspace slice
 
 __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
@@ -1677,6 +1691,96 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+// Rows (segments of more than 128 elements) with the per-segment output summed in numpy's order: the float32 mean
+// squared error of a row has the BITS of np.mean(diff * diff) over that row (compute_mse on a row slice,
+// quant_error_single_weight.py:46-48, :56-60).  A wave per row; the row is read twice (reduction, then the errors:
+// the second read comes from L2).  Lane l adds up whole leaves of numpy's split tree (b.np) -- eight accumulators
+// r[i] += a[8 k + i] over the leaf's vectors in memory order, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+// -- and lane 0 combines the leaf sums in the tree's order.  np.mean divides the float32 sum by the count in
+// float64 and rounds to float32: one correctly rounded float32 division.  A correctness mode, not a bandwidth
+// path: the leaves' strided reads and the one-lane combine leave most of the machine idle.
+template <int FMT, bool BF16>
+__global__ __launch_bounds__(256) void k_rows_numpy(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
+  __shared__ double lds[32];
+  __shared__ float leaf_sum[4][MQ_NP_MAX_LEAVES];
+  __shared__ uint16_t leaf_off[MQ_NP_MAX_LEAVES];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (int i = 0; i < b.np.nleaves; ++i) { leaf_off[i] = (uint16_t)o; o += b.np.len[i]; }
+  }
+  __syncthreads();
+  const char* wb = static_cast<const char*>(p.w);
+  const int64_t row_bytes = p.L * 2;
+  double acc_sse = 0.0, acc_abs = 0.0;
+  for (int64_t row = (int64_t)p.bx * 4 + wv; row < p.nseg; row += (int64_t)p.gx * 4) {
+    const char* rp = wb + row * row_bytes;
+    uint32_t red = FMT == MQ_INT_ASYM ? 0xfc007c00u : 0u;  // (+inf, -inf) resp. 0: neutral
+    for (int v = lane; v < p.vecs_per_seg; v += 64) {
+      u32x4 one[1] = {stats_cvt<BF16>(*reinterpret_cast<const u32x4*>(rp + (int64_t)v * 16))};
+      red = stats_op<FMT>(red, stats_lane_reduce<FMT, 1>(one));
+    }
+    const SegP sp = stats_params<FMT>(team_reduce_u32<64>(red, stats_op<FMT>), p);
+    for (int leaf = lane; leaf < b.np.nleaves; leaf += 64) {
+      float r[8];
+      const int nv = b.np.len[leaf];
+      const char* lp = rp + (int64_t)leaf_off[leaf] * 16;
+#pragma unroll 1
+      for (int k = 0; k < nv; ++k) {
+        const u32x4 raw = stats_cvt<BF16>(*reinterpret_cast<const u32x4*>(lp + k * 16));
+        float sq[8];
+        if (!sp.slow) {
+          float q = 0.f, ab = 0.f;
+          quant8_stats<FMT, true, true>(p, raw, sp, q, ab, sq);
+          acc_sse += (double)q;
+          acc_abs += (double)ab;
+        } else {
+          Acc acc;
+          acc.abs = 0.0;
+          acc.xp = nullptr;
+          acc.sq = sq;
+          acc_sse += quant8_slow<FMT, SEL_STATS_ONLY>(p, raw, sp, 0, acc);
+          acc_abs += acc.abs;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = k == 0 ? sq[i] : r[i] + sq[i];
+      }
+      leaf_sum[wv][leaf] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0) {
+      float st[12];  // (the tree is at most ten levels deep for 512 leaves)
+      int top = 0, next = 0;
+#pragma unroll 1
+      for (int i = 0; i < b.np.nops; ++i) {
+        if ((b.np.ops[i >> 5] >> (i & 31)) & 1u) {
+          // st[top - 2] + st[top - 1] without indexing the register array by a variable twice over
+          float x = 0.f, y = 0.f;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) { x = j == top - 2 ? st[j] : x; y = j == top - 1 ? st[j] : y; }
+          const float z = x + y;
+#pragma unroll
+          for (int j = 0; j < 12; ++j) st[j] = j == top - 2 ? z : st[j];
+          --top;
+        } else {
+          const float z = leaf_sum[wv][next++];
+#pragma unroll
+          for (int j = 0; j < 12; ++j) st[j] = j == top ? z : st[j];
+          ++top;
+        }
+      }
+      if (p.seg_sse) reinterpret_cast<float*>(p.seg_sse)[row] = st[0] / (float)p.L;
+      if (p.scale) p.scale[row] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[row] = (uint16_t)h_bits(sp.zp);
+    }
+    __builtin_amdgcn_wave_barrier();  // (lane 0 has read the leaf sums before the next row's are written)
+  }
+  block_partials(p, acc_sse, acc_abs, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // SC_TENSOR: group_size == -1.  k_tensor_reduce leaves the tensor's absmax / min / max in tred[];
 // k_quant_tensor then treats the flat tensor as one segment whose parameters every lane derives itself.
@@ -2045,7 +2149,9 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
 template <int FMT, bool BF16>
 static void launch_stats(int scope, int nv, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
 #define MQ_STATS_ROW(NV, WPR) hipLaunchKernelGGL((k_stats_row<FMT, BF16, NV, WPR>), grid, dim3(256), 0, st, p)
-  if (scope == SC_STATS_GROUP && p.common.seg_exact) {  // (the host admits team_log2 <= 2 only)
+  if (scope == SC_STATS_ROWNP) {
+    hipLaunchKernelGGL((k_rows_numpy<FMT, BF16>), grid, dim3(256), 0, st, p);
+  } else if (scope == SC_STATS_GROUP && p.common.seg_exact) {  // (the host admits team_log2 <= 2 only)
     switch (team_log2) {
       case 0: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 1, true>), grid, dim3(256), 0, st, p); break;
       case 1: hipLaunchKernelGGL((k_stats_group<FMT, BF16, 2, true>), grid, dim3(256), 0, st, p); break;
@@ -2208,6 +2314,39 @@ static int prof_next_pair(hipEvent_t* e0, hipEvent_t* e1) {
 // batch: 1024 .. 3072 workgroups (every wave resident for the whole launch, looping over many tiles) run the
 // full pass in ~518 us, 8192 in ~490 us, 32768 and more lose again (per-workgroup epilogues).  MQ_MAX_BLOCKS
 // overrides it for tuning runs.
+// numpy's split of a run of n elements (see NumpyProg); false if it does not fit the program.
+static bool numpy_prog(int64_t n, NumpyProg* pr) {
+  *pr = NumpyProg{};
+  if (n < 8 || n % 8 || n > 32768) return false;
+  bool ok = true;
+  auto op = [&](uint32_t bit) {
+    if (pr->nops >= 2 * MQ_NP_MAX_LEAVES) { ok = false; return; }
+    pr->ops[pr->nops >> 5] |= bit << (pr->nops & 31);
+    ++pr->nops;
+  };
+  auto rec = [&](auto&& self, int64_t m) -> void {
+    if (!ok) return;
+    if (m <= 128) {
+      if (pr->nleaves >= MQ_NP_MAX_LEAVES) { ok = false; return; }
+      pr->len[pr->nleaves++] = (uint8_t)(m / 8);
+      op(0u);
+    } else {
+      int64_t n2 = m / 2;
+      n2 -= n2 % 8;
+      self(self, n2);
+      self(self, m - n2);
+      op(1u);
+    }
+  };
+  // np.add.reduce hands its inner loop at most 8192 elements at a time (numpy's default buffer size,
+  // np.getbufsize()) and adds the chunks' pairwise sums in order
+  for (int64_t off = 0; off < n; off += 8192) {
+    rec(rec, n - off < 8192 ? n - off : 8192);
+    if (off) op(1u);
+  }
+  return ok;
+}
+
 static int64_t grid_cap() {
   static const int64_t cap = [] {
     const char* e = getenv("MQ_MAX_BLOCKS");
@@ -2411,17 +2550,27 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   // (... and a tensor inside the 32-bit offsets of the buffer loads)
   const bool stats_kernels = kmode == SEL_STATS_ONLY && vec_ok && (w_dtype == MQ_F16 || w_dtype == MQ_BF16) &&
                              !(fmt == MQ_LUT_FP && cfg->man_bits > 6) && n * 2 <= 0xf0000000ll;
-  if (kmode == SEL_STATS_ONLY && scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0 && !sampled) {
+  const bool pow2_group = scope == SC_SUBWAVE && p.L % 32 == 0 && ((p.L / 32) & (p.L / 32 - 1)) == 0;
+  if (kmode == SEL_STATS_ONLY && pow2_group && !sampled && !(p.seg_exact && p.L > 128)) {
     // groups of 32 * 2^k elements: the kernels that hold four vectors of one segment per lane
     team_log2 = ilog2_ceil(p.L / 32);
     nv = -4;
     if (stats_kernels) scope = SC_STATS_GROUP;
-    if (p.seg_exact && !(stats_kernels && team_log2 <= 2)) return MQ_ERR_UNSUPPORTED;
+    if (p.seg_exact && !stats_kernels) return MQ_ERR_UNSUPPORTED;
     const int64_t spw = 64 >> team_log2;
     const int64_t wb = ((p.nseg + spw - 1) / spw + 3) / 4;
     grid.x = (unsigned)(wb < max_grid ? wb : max_grid);
   } else if (p.seg_exact) {
-    return MQ_ERR_UNSUPPORTED;  // numpy-order entries: statistics-only groups of 32 / 64 / 128 elements
+    // numpy-order entries of every other segment length (rows, groups that are not 32 / 64 / 128 elements): the
+    // wave-per-segment kernel that walks numpy's split tree
+    if (!(stats_kernels && (scope == SC_SUBWAVE || scope == SC_WAVE || scope == SC_BLOCK) && p.L <= 32768 &&
+          numpy_prog(p.L, &b.np)))
+      return MQ_ERR_UNSUPPORTED;
+    scope = SC_STATS_ROWNP;
+    const int64_t wb = (p.nseg + 3) / 4;
+    int64_t cap = grid_cap();
+    if (count > 1) cap = cap / count < 64 ? 64 : cap / count;
+    grid.x = (unsigned)(wb < cap ? wb : cap);
   } else if (stats_kernels && (scope == SC_WAVE || scope == SC_BLOCK) && p.L / 8 <= 4096) {
     const int64_t vecs = p.L / 8;
     int64_t wb;

@@ -144,8 +144,8 @@ def quantize(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, datatype
     abs_err: None, torch.float32 or torch.float16.  seg_sse: float64 sums of squared errors per segment; seg_mse:
     the float32 mean squared error per segment instead (the per-vector MSE list of
     quant_error_single_weight.py:56-71, whose entries are float32 means) -- one of the two.  seg_mse="numpy": the
-    entries are summed in numpy's pairwise order and equal np.mean(diff * diff) bit for bit (statistics-only calls
-    with groups of 32 / 64 / 128 elements; ValueError otherwise).  `out` may carry
+    entries are summed in numpy's order and equal np.mean(diff * diff) bit for bit (statistics-only calls on float16 /
+    bfloat16 weights, segments of a multiple of 8 and at most 32768 elements; ValueError otherwise).  `out` may carry
     preallocated tensors to reuse.
     """
     if seg_sse and seg_mse:

@@ -107,9 +107,12 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     a weight has the same length, so the two are the same number up to the float32 rounding of the list entries
     (6e-8 relative), and no pass over the list is needed for it.
 
-    numpy_order (groups of 32 / 64 / 128 elements, abs_p99=False): the list entries are summed in numpy's pairwise
-    order and have the bits of the scripts' entries, so mse_p99 equals the reference's float(np.percentile(vec, 99))
-    bit for bit (the kernels spend ~T more float32 additions per element pair for it; mse_rep stays as above)."""
+    numpy_order (abs_p99=False; float16 / bfloat16 weights, per-channel or per-group with segments of a multiple of
+    8 and at most 32768 elements): the list entries are summed in numpy's order -- pairwise, in chunks of 8192
+    elements -- and have the bits of the scripts' entries, so mse_p99 equals the reference's
+    float(np.percentile(vec, 99)) bit for bit.  Groups of 32 / 64 / 128 elements stay in the bandwidth kernels (~T more
+    float32 additions per element pair); rows and other group sizes take a wave-per-segment kernel that is several
+    times slower.  mse_rep stays as above."""
     fmt, table = format_code(datatype)
     weights = list(weights)
     if not weights:
@@ -200,7 +203,8 @@ class SweepPlan:
     single_launch=False: everything does).  The selections of pass k -- chains of short launches that leave most of
     the chip idle -- run on a second HIP stream while the current stream already streams the weights for pass
     k + 1; the streams are joined before run() returns, so the result is ordered on the current stream.
-    numpy_order: as for model_records (every pass must then be per-group with 32 / 64 / 128 elements)."""
+    numpy_order: as for model_records (per-channel passes and group sizes other than 32 / 64 / 128 then go through the
+    batched launches and the slower wave-per-segment kernel)."""
 
     def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True):
         import ctypes

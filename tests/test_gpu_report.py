@@ -104,17 +104,17 @@ def test_model_records_vs_oracle(oracle):
                 assert v.dtype == np.float32 and v.size == w.size // (gs or w.shape[1])
                 # the selection itself is exact: np.percentile of the list the kernel wrote
                 assert rec[i, 4] == np.percentile(v.astype(np.float64), 99)
-            if gs is not None:
-                # numpy_order: the list entries have numpy's bits, so mse_p99 is the reference's value bit for bit
-                for make in (lambda: report.model_records(ws, datatype, 8, gs, abs_p99=False, numpy_order=True),
-                             lambda: report.SweepPlan(ws, [(datatype, 8, gs)], numpy_order=True).run()[0]):
-                    ex = make().cpu().numpy()
-                    for i, w in enumerate(w16):
-                        ce, _ = _np_record(oracle, w, datatype, gs, "single")
-                        assert ex[i, 4] == ce["mse_p99"], (datatype, gs, i)
-                        assert abs(ex[i, 3] - ce["mse_rep"]) <= 1e-6 * ce["mse_rep"]
-    with pytest.raises(ValueError):
-        report.model_records(ws, "int8", 8, None, abs_p99=False, numpy_order=True)   # rows: not offered
+            # numpy_order: the list entries have numpy's bits, so mse_p99 is the reference's value bit for bit --
+            # per-group and per-channel (rows go through the wave-per-segment kernel)
+            for make in (lambda: report.model_records(ws, datatype, 8, gs, abs_p99=False, numpy_order=True),
+                         lambda: report.SweepPlan(ws, [(datatype, 8, gs)], numpy_order=True).run()[0]):
+                ex = make().cpu().numpy()
+                for i, w in enumerate(w16):
+                    ce, _ = _np_record(oracle, w, datatype, gs, "single")
+                    assert ex[i, 4] == ce["mse_p99"], (datatype, gs, i)
+                    assert abs(ex[i, 3] - ce["mse_rep"]) <= 1e-6 * ce["mse_rep"]
+    with pytest.raises(ValueError):   # float32 weights: not offered in numpy's order
+        report.model_records([w.float() for w in ws], "int8", 8, None, abs_p99=False, numpy_order=True)
 
 
 def _worker(rank, world, port, q):

@@ -213,9 +213,47 @@ def test_numpy_order_list_entries_are_bit_exact(oracle, fmt, dt):
         assert got.dtype == np.float32 and got.shape == want.shape
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), (name, dt, rows, cols, gs, int((~same).sum()), got[~same][:4], want[~same][:4])
-    with pytest.raises(ValueError):   # rows, groups beyond 128, calls with element outputs: not offered
-        quantize(wt.cuda(), code, bits, None, table, deq=False, codes=False, scale=False, seg_mse="numpy")
-    with pytest.raises(ValueError):
-        quantize(wt.cuda(), code, bits, 256, table, deq=False, codes=False, scale=False, seg_mse="numpy")
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):   # calls with element outputs: not offered
         quantize(wt.cuda(), code, bits, 128, table, deq=True, codes=False, scale=False, seg_mse="numpy")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("fmt", FORMATS, ids=[f[0] for f in FORMATS])
+def test_numpy_order_row_entries_are_bit_exact(oracle, fmt, dt):
+    """seg_mse="numpy" on rows (per-channel, and groups longer than 512 elements): every entry has the BITS of
+    float(np.mean(diff * diff)) over the row slice (quant_error_single_weight.py:46-48, :56-60) -- numpy's pairwise
+    summation with its split of runs longer than 128 elements, numpy itself as judge.  Row lengths: powers of two,
+    the Llama widths (14336 = 128 leaves of 112; 11008 and 5632 split into unequal leaves), lengths that are only
+    a multiple of 8, one past the inner-loop size of numpy's reduction (8192), and a long group."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    name, bits = fmt
+    cases = [(9, 4096, None), (5, 14336, None), (4, 11008, None), (6, 5632, None), (7, 1000, None), (3, 28672, None),
+             (5, 520, None), (2, 32768, None), (4, 2600, None), (6, 4096, 1024), (5, 2048, 256), (3, 1536, 512),
+             (7, 960, 96), (4, 200, None), (9, 1024, 8), (3, 480, 40)]
+    for k, (rows, cols, gs) in enumerate(cases):
+        w = _inputs(rows, cols, 900 + k)
+        wt = w.half() if dt == "f16" else w.bfloat16()
+        (code, table), oargs = _fmt(oracle, _lib, name, bits)
+        res = quantize(wt.cuda(), code, bits, gs, table, deq=False, codes=False, scale=True, seg_mse="numpy", totals=True)
+        ref = quantize(wt.cuda(), code, bits, gs, table, deq=False, codes=False, scale=True, seg_mse=True, totals=True)
+        raw = wt.view(torch.int16).numpy().view(np.uint16)
+        exp = oracle.quantize(raw, oracle.F16 if dt == "f16" else oracle.BF16, group_size=gs, **oargs)
+        a = wt.half().float().numpy()
+        b = exp["deq"].view(np.float16).astype(np.float32).reshape(rows, cols)
+        L = gs or cols
+        with np.errstate(invalid="ignore", over="ignore"):
+            want = np.array([np.mean((a[r, g:g + L] - b[r, g:g + L]) * (a[r, g:g + L] - b[r, g:g + L]))
+                             for r in range(rows) for g in range(0, cols, L)], dtype=np.float32)
+        got = res.seg_mse.cpu().numpy()
+        assert got.dtype == np.float32 and got.shape == want.shape
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (name, dt, rows, cols, gs, int((~same).sum()), got[~same][:4], want[~same][:4])
+        # scales: those of the bandwidth kernels; totals: float32 partial sums over other runs of elements, the
+        # 1e-6 bar of every sum (NaN alike)
+        assert torch.equal(res.scale.view(torch.int16), ref.scale.view(torch.int16))
+        x, y = res.totals, ref.totals
+        assert bool(((x == y) | (x.isnan() & y.isnan()) | ((x - y).abs() <= 1e-6 * y.abs())).all()), (x, y)
+    with pytest.raises(ValueError):   # past the longest row the split program holds
+        quantize(torch.zeros(2, 65536, dtype=torch.float16, device="cuda"), code, bits, None, table, deq=False,
+                 codes=False, scale=False, seg_mse="numpy")
