@@ -176,6 +176,16 @@ int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t 
                  const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
 /*
+ * mse_rep in numpy's bits: out[i][0] = np.array(list_i, dtype=float64).mean() for `count` float32 lists of n values
+ * each -- vec = np.array(per_vec); float(vec.mean()) of quant_error_single_weight.py:74-78, whose entries are
+ * float32 means held in a float64 array -- summed in float64 in numpy's order (chunks of 8192 elements added in
+ * order, each chunk pairwise down to leaves of at most 128 elements with eight strided accumulators) and divided by
+ * n.  lists / out: HOST arrays of device pointers (float32 [n], 4-byte aligned; one float64 each).  One workgroup
+ * per list, 64 lists per launch: a correctness mode for report.*(numpy_order=True), not a bandwidth path.
+ */
+int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, double* const* out, void* hip_stream);
+
+/*
  * The report rows of one pass (the CSV rows of quant_error_multi_weight.py:142-151 before formatting): for tensor i
  * of `count`, records[perm[i]][0..5] = numel[i], totals[i][0] (sum of squared errors), totals[i][1] (sum of |error|),
  * totals[i][0] / numel[i] (mse_tensor = mse_rep, IEEE float64 division), p99[i] (mse_p99; NaN when the mean is NaN,

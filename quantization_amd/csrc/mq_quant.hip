@@ -1691,6 +1691,35 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+// Runs a post-order program of numpy's split tree (see NumpyProg) over the leaves' sums: bit 0 takes the next leaf's
+// sum, bit 1 adds the two newest partial sums (the older one on the left).  One lane; the stack lives in registers
+// (selected by compare chains, not indexed: an indexed register array would go to scratch memory).
+template <typename T, typename LeafPtr>
+__device__ __forceinline__ T numpy_run_prog(const uint32_t* ops, int nops, LeafPtr leaves) {
+  T st[12];  // (at most ten levels for 512 leaves)
+#pragma unroll
+  for (int j = 0; j < 12; ++j) st[j] = (T)0;
+  int top = 0, next = 0;
+#pragma unroll 1
+  for (int i = 0; i < nops; ++i) {
+    if ((ops[i >> 5] >> (i & 31)) & 1u) {
+      T x = (T)0, y = (T)0;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) { x = j == top - 2 ? st[j] : x; y = j == top - 1 ? st[j] : y; }
+      const T z = x + y;
+#pragma unroll
+      for (int j = 0; j < 12; ++j) st[j] = j == top - 2 ? z : st[j];
+      --top;
+    } else {
+      const T z = leaves[next++];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) st[j] = j == top ? z : st[j];
+      ++top;
+    }
+  }
+  return st[0];
+}
+
 // Rows (segments of more than 128 elements) with the per-segment output summed in numpy's order: the float32 mean
 // squared error of a row has the BITS of np.mean(diff * diff) over that row (compute_mse on a row slice,
 // quant_error_single_weight.py:46-48, :56-60).  A wave per row; the row is read twice (reduction, then the errors:
@@ -1752,27 +1781,8 @@ __global__ __launch_bounds__(256) void k_rows_numpy(const QuantBatch b) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (lane == 0) {
-      float st[12];  // (the tree is at most ten levels deep for 512 leaves)
-      int top = 0, next = 0;
-#pragma unroll 1
-      for (int i = 0; i < b.np.nops; ++i) {
-        if ((b.np.ops[i >> 5] >> (i & 31)) & 1u) {
-          // st[top - 2] + st[top - 1] without indexing the register array by a variable twice over
-          float x = 0.f, y = 0.f;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) { x = j == top - 2 ? st[j] : x; y = j == top - 1 ? st[j] : y; }
-          const float z = x + y;
-#pragma unroll
-          for (int j = 0; j < 12; ++j) st[j] = j == top - 2 ? z : st[j];
-          --top;
-        } else {
-          const float z = leaf_sum[wv][next++];
-#pragma unroll
-          for (int j = 0; j < 12; ++j) st[j] = j == top ? z : st[j];
-          ++top;
-        }
-      }
-      if (p.seg_sse) reinterpret_cast<float*>(p.seg_sse)[row] = st[0] / (float)p.L;
+      const float total = numpy_run_prog<float>(b.np.ops, b.np.nops, &leaf_sum[wv][0]);
+      if (p.seg_sse) reinterpret_cast<float*>(p.seg_sse)[row] = total / (float)p.L;
       if (p.scale) p.scale[row] = (uint16_t)h_bits(sp.s);
       if (FMT == MQ_INT_ASYM && p.zp) p.zp[row] = (uint16_t)h_bits(sp.zp);
     }
@@ -2027,6 +2037,67 @@ __global__ __launch_bounds__(256) void k_finalize_sweep(const QuantBatch b) {
     it.totals[0] = x;
     it.totals[1] = y;
   }
+}
+
+// np.mean of the float64 array that holds a list of float32 values (vec = np.array(per_vec); vec.mean():
+// quant_error_single_weight.py:74-78), in numpy's summation order: chunks of 8192 elements added in order, each
+// chunk pairwise with leaves of at most 128 elements (see NumpyProg), the sum divided by the count in float64.
+// full / tail: the split programs of a whole chunk and of the last, shorter one (leaf lengths in ELEMENTS here).
+struct ListProg {
+  uint16_t nleaves, nops;
+  uint8_t len[128];
+  uint32_t ops[8];
+};
+#define MQ_LIST_BATCH 64
+struct ListBatch {
+  const float* x[MQ_LIST_BATCH];
+  double* out[MQ_LIST_BATCH];
+  int64_t n;  // every list of a launch has this length
+  ListProg full, tail;
+};
+__device__ __forceinline__ double numpy_leaf_f64(const float* a, int n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int i = 0; i < n; ++i) res += (double)a[i];
+    return res;
+  }
+  double r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (double)a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] += (double)a[i + j];
+  }
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += (double)a[i];
+  return res;
+}
+__global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
+  __shared__ double leaf[128];
+  __shared__ uint16_t off_full[128], off_tail[128];
+  const float* x = b.x[blockIdx.x];
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (int i = 0; i < b.full.nleaves; ++i) { off_full[i] = (uint16_t)o; o += b.full.len[i]; }
+    o = 0;
+    for (int i = 0; i < b.tail.nleaves; ++i) { off_tail[i] = (uint16_t)o; o += b.tail.len[i]; }
+  }
+  __syncthreads();
+  double total = 0.0;  // (thread 0's; 0 + x = x: the first chunk's sum as it is)
+  for (int64_t c0 = 0; c0 < b.n; c0 += 8192) {
+    const bool is_tail = b.n - c0 < 8192;
+    const ListProg& pr = is_tail ? b.tail : b.full;
+    const uint16_t* off = is_tail ? off_tail : off_full;
+    if ((int)threadIdx.x < pr.nleaves) leaf[threadIdx.x] = numpy_leaf_f64(x + c0 + off[threadIdx.x], pr.len[threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double c = numpy_run_prog<double>(pr.ops, pr.nops, &leaf[0]);
+      total = c0 == 0 ? c : total + c;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *b.out[blockIdx.x] = total / (double)b.n;
 }
 
 // The record rows of one pass of a sweep (numel, sse, sum |err|, mean squared error, P99 of the per-vector list, 0),
@@ -2344,6 +2415,34 @@ static bool numpy_prog(int64_t n, NumpyProg* pr) {
     rec(rec, n - off < 8192 ? n - off : 8192);
     if (off) op(1u);
   }
+  return ok;
+}
+
+// the split program of one chunk of m <= 8192 elements, leaf lengths in elements (any m >= 1)
+static bool list_prog(int64_t m, ListProg* pr) {
+  *pr = ListProg{};
+  if (m < 1 || m > 8192) return m == 0;
+  bool ok = true;
+  auto op = [&](uint32_t bit) {
+    if (pr->nops >= 256) { ok = false; return; }
+    pr->ops[pr->nops >> 5] |= bit << (pr->nops & 31);
+    ++pr->nops;
+  };
+  auto rec = [&](auto&& self, int64_t k) -> void {
+    if (!ok) return;
+    if (k <= 128) {
+      if (pr->nleaves >= 128) { ok = false; return; }
+      pr->len[pr->nleaves++] = (uint8_t)k;
+      op(0u);
+    } else {
+      int64_t n2 = k / 2;
+      n2 -= n2 % 8;
+      self(self, n2);
+      self(self, k - n2);
+      op(1u);
+    }
+  };
+  rec(rec, m);
   return ok;
 }
 
@@ -2773,6 +2872,26 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
   if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
   hipLaunchKernelGGL(k_finalize_sweep, dim3((unsigned)count), dim3(256), 0, st, b);
   MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+extern "C" int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, double* const* out,
+                                  void* hip_stream) {
+  if (count < 0 || n < 1 || (count > 0 && (!lists || !out))) return MQ_ERR_ARG;
+  ListBatch b = {};
+  b.n = n;
+  if (!list_prog(n < 8192 ? 0 : 8192, &b.full) || !list_prog(n % 8192, &b.tail)) return MQ_ERR_UNSUPPORTED;
+  for (int32_t done = 0; done < count; done += MQ_LIST_BATCH) {
+    const int32_t c = count - done < MQ_LIST_BATCH ? count - done : MQ_LIST_BATCH;
+    for (int32_t i = 0; i < c; ++i) {
+      if (!lists[done + i] || !out[done + i]) return MQ_ERR_ARG;
+      if (!aligned(lists[done + i], 4) || !aligned(out[done + i], 8)) return MQ_ERR_ALIGN;
+      b.x[i] = static_cast<const float*>(lists[done + i]);
+      b.out[i] = out[done + i];
+    }
+    hipLaunchKernelGGL(k_list_mean_numpy, dim3((unsigned)c), dim3(128), 0, static_cast<hipStream_t>(hip_stream), b);
+    MQ_HIP(hipGetLastError());
+  }
   return MQ_OK;
 }
 

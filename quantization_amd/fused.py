@@ -233,6 +233,8 @@ def bind_batch():
                                         ctypes.POINTER(_lib.QuantCfg), vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L_.mq_sweep_run.restype = ctypes.c_int
         L_.mq_sweep_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), i32, vp, sz, vp]
+        L_.mq_list_mean_numpy.restype = ctypes.c_int
+        L_.mq_list_mean_numpy.argtypes = [ctypes.POINTER(vp), i32, i64, ctypes.POINTER(vp), vp]
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

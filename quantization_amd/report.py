@@ -112,7 +112,8 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
     elements -- and have the bits of the scripts' entries, so mse_p99 equals the reference's
     float(np.percentile(vec, 99)) bit for bit.  Groups of 32 / 64 / 128 elements stay in the bandwidth kernels (~T more
     float32 additions per element pair); rows and other group sizes take a wave-per-segment kernel that is several
-    times slower.  mse_rep stays as above."""
+    times slower.  mse_rep is then the float64 mean of the list in numpy's summation order (numpy_list_means): the
+    reference's float(vec.mean()) bit for bit; the tensor sums (numel, sse, sum_abs) stay as above."""
     fmt, table = format_code(datatype)
     weights = list(weights)
     if not weights:
@@ -126,6 +127,10 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         raise ValueError("numpy_order is a statistics-only mode: pass abs_p99=False")
     state = _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes, numpy_order)
     out = _finish_pass(weights, state, abs_p99, pct)
+    if numpy_order:   # mse_rep in numpy's bits: the float64 mean of the list, in numpy's summation order
+        vecs = [v for r in state[1] for v in r.seg_mse.unbind(0)]
+        rep = numpy_list_means(vecs)
+        out[torch.as_tensor(state[0], device=out.device), 3] = rep
     if return_vecs:
         vec_rows, keep = state[0], state[1]
         vecs = [v for r in keep for v in r.seg_mse.unbind(0)]
@@ -185,6 +190,29 @@ def _finish_pass(weights, state, abs_p99, pct):
     return out
 
 
+def numpy_list_means(lists, stream=None) -> torch.Tensor:
+    """float(np.array(v, dtype=float64).mean()) for every float32 list v of `lists`, bit for bit (numpy's float64
+    summation order; mq_list_mean_numpy): the scripts' mse_rep = float(vec.mean()) (quant_error_single_weight.py:78).
+    -> float64 [len(lists)] on the lists' device, enqueued on `stream` (default: the current one)."""
+    import ctypes
+    from .fused import bind_batch
+    L = bind_batch()
+    lists = list(lists)
+    dev = lists[0].device
+    out = torch.empty(len(lists), dtype=torch.float64, device=dev)
+    st = (stream or torch.cuda.current_stream(dev)).cuda_stream
+    by_n: Dict[int, List[int]] = {}
+    for i, v in enumerate(lists):
+        if v.dtype != torch.float32 or not v.is_contiguous() or v.dim() != 1 or v.numel() == 0:
+            raise ValueError("numpy_list_means takes non-empty contiguous 1-D float32 lists")
+        by_n.setdefault(v.numel(), []).append(i)
+    for n, idx in by_n.items():
+        xs = (ctypes.c_void_p * len(idx))(*[lists[i].data_ptr() for i in idx])
+        os_ = (ctypes.c_void_p * len(idx))(*[out.data_ptr() + 8 * i for i in idx])
+        _lib.check(L.mq_list_mean_numpy(xs, len(idx), n, os_, st))
+    return out
+
+
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -213,6 +241,7 @@ class SweepPlan:
         self.weights = list(weights)
         self.passes = list(passes)
         self.pct = float(pct)
+        self.numpy_order = bool(numpy_order)
         if not self.weights or not self.passes:
             raise ValueError("SweepPlan needs at least one weight and one pass")
         dev = self.dev = self.weights[0].device
@@ -358,6 +387,8 @@ class SweepPlan:
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
                                                   self.perm.data_ptr(), nl, self.records[k].data_ptr(),
                                                   side.cuda_stream))
+                    if self.numpy_order:   # mse_rep in numpy's bits (the lists in the order of `weights`)
+                        self.records[k][:, 3] = numpy_list_means(ps["lists"], side)
             self._pending = (main, side)
 
     @torch.no_grad()

@@ -112,7 +112,8 @@ def test_model_records_vs_oracle(oracle):
                 for i, w in enumerate(w16):
                     ce, _ = _np_record(oracle, w, datatype, gs, "single")
                     assert ex[i, 4] == ce["mse_p99"], (datatype, gs, i)
-                    assert abs(ex[i, 3] - ce["mse_rep"]) <= 1e-6 * ce["mse_rep"]
+                    assert ex[i, 3] == ce["mse_rep"], (datatype, gs, i)   # float(vec.mean()) in numpy's order
+                    assert abs(ex[i, 1] / ex[i, 0] - ce["mse_tensor"]) <= 1e-6 * ce["mse_tensor"]
     with pytest.raises(ValueError):   # float32 weights: not offered in numpy's order
         report.model_records([w.float() for w in ws], "int8", 8, None, abs_p99=False, numpy_order=True)
 
@@ -395,3 +396,21 @@ def test_single_launch_sweep_equals_per_shape_batches():
         assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(one.lists(0), per.lists(0)))
         assert torch.equal(a[0][:, 4].view(torch.int64), b[0][:, 4].view(torch.int64))
     torch.cuda.synchronize()
+
+
+def test_numpy_list_means_have_numpys_bits():
+    """report.numpy_list_means: np.array(v, dtype=float64).mean() of float32 lists, bit for bit -- lengths below 8,
+    around the leaf size (128), around and far beyond the 8192-element chunks of numpy's reduction, odd lengths;
+    values spanning many binades; a list holding a NaN."""
+    from quantization_amd import report
+    rng = np.random.default_rng(17)
+    lens = [1, 5, 7, 8, 9, 100, 127, 128, 129, 255, 1000, 4096, 8191, 8192, 8193, 8200, 12345, 16384, 128256, 1048579,
+            4096, 4096, 128256]
+    lists = [(rng.standard_normal(n) ** 2 * 10.0 ** rng.uniform(-9, -5)).astype(np.float32) for n in lens]
+    lists[3][2] = np.nan
+    dev = [torch.from_numpy(v).cuda() for v in lists]
+    got = report.numpy_list_means(dev).cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        want = np.array([v.astype(np.float64).mean() for v in lists])
+    same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), [(lens[i], got[i], want[i]) for i in np.nonzero(~same)[0]]
