@@ -176,6 +176,23 @@ int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t 
                  const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
 /*
+ * mse_tensor in numpy's bits: mse_out[0] = float32 np.mean((a32 - b32) ** 2) over the whole [rows, cols] tensor
+ * (compute_mse, quant_error_multi_weight.py:55-58), a32 the float16-rounded weight and b32 its dequantized value:
+ * the float32 squares summed in numpy's order over the FLATTENED tensor -- chunks of 8192 elements added in order,
+ * each chunk pairwise down to leaves of at most 128 elements -- and divided by the count in float64.  The chunks
+ * cross rows and groups, so the segments' parameters are inputs: scale (and zero_point for MQ_INT_ASYM), float16
+ * [nseg], as a statistics pass of mq_quantize / mq_sweep_run wrote them for this weight and configuration.
+ * float16 / bfloat16 weights, 16-byte aligned, segment length a multiple of 8, at most 2^29 elements
+ * (MQ_ERR_UNSUPPORTED otherwise).  workspace: mq_tensor_mse_numpy_workspace_bytes(rows, cols).  Two launches; a
+ * correctness mode for report.*(numpy_order=True) -- every element takes the per-element routine -- not a bandwidth
+ * path.
+ */
+size_t mq_tensor_mse_numpy_workspace_bytes(int64_t rows, int64_t cols);
+int mq_tensor_mse_numpy(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
+                        const void* scale, const void* zero_point, float* mse_out, void* workspace,
+                        size_t workspace_bytes, void* hip_stream);
+
+/*
  * mse_rep in numpy's bits: out[i][0] = np.array(list_i, dtype=float64).mean() for `count` float32 lists of n values
  * each -- vec = np.array(per_vec); float(vec.mean()) of quant_error_single_weight.py:74-78, whose entries are
  * float32 means held in a float64 array -- summed in float64 in numpy's order (chunks of 8192 elements added in

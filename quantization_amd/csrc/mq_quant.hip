@@ -38,7 +38,7 @@
 enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3,
        // the statistics-only kernels (k_stats_*): groups of 32 * 2^team_log2 elements; rows held by one wave / by
        // a 256-thread workgroup with nv vectors per lane
-       SC_STATS_GROUP = 4, SC_STATS_ROW = 5, SC_STATS_ROWBLK = 6, SC_STATS_ROWNP = 7 };
+       SC_STATS_GROUP = 4, SC_STATS_ROW = 5, SC_STATS_ROWBLK = 6, SC_STATS_ROWNP = 7, SC_TENSOR_NP = 8 };
 // The kernels' SEL template parameter: one of the SEL_FEED_* values, or SEL_STATS_ONLY = no selection feed and no
 // element-sized output (deq / codes / abs_err all absent: the sweeps that only want the error statistics), which
 // drops the per-vector tests of the output pointers and everything that only served the stores.
@@ -1791,6 +1791,79 @@ __global__ __launch_bounds__(256) void k_rows_numpy(const QuantBatch b) {
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+// The float32 sum of squared errors over the whole flattened tensor in numpy's order -- what np.mean((a32 - b32) ** 2)
+// of compute_mse adds up for a 2-D array (quant_error_multi_weight.py:55-58): chunks of 8192 elements, each summed
+// pairwise (64 leaves of 128 elements in a whole chunk; b.np: the split of the last, shorter chunk).  The chunks
+// cross rows and groups, so the segments' parameters come from a pass that ran before: p.scale / p.zp are INPUTS
+// here, and every element goes through the per-element routine (quant8_slow: the contract literally, equal to the
+// fast paths wherever those apply).  A wave per chunk, a lane per leaf; chunk sums go to the workspace as float32
+// [chunks], k_tensor_mse_finish adds them in order.  A correctness mode, not a bandwidth path.
+template <int FMT, bool BF16>
+__global__ __launch_bounds__(256) void k_tensor_mse_numpy(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
+  __shared__ float leaf_sum[4][128];
+  __shared__ uint16_t leaf_off[128];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (int i = 0; i < b.np.nleaves; ++i) { leaf_off[i] = (uint16_t)o; o += b.np.len[i]; }
+  }
+  __syncthreads();
+  const int64_t nfull = p.n / 8192, nchunks = nfull + (p.n % 8192 ? 1 : 0);
+  float* cs = reinterpret_cast<float*>(p.partials);
+  const char* wb = static_cast<const char*>(p.w);
+  auto leaf = [&](int64_t e0, int nv) __attribute__((always_inline)) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < nv; ++k) {
+      const int64_t e = e0 + (int64_t)k * 8, seg = e / p.L;
+      SegP sp;
+      sp.s = h_from_bits(p.scale[seg]);
+      sp.sf = (float)sp.s;
+      sp.r = 1.0f / sp.sf;
+      sp.zp = FMT == MQ_INT_ASYM ? h_from_bits(p.zp[seg]) : (half_t)0;
+      sp.slow = true;
+      const u32x4 raw = stats_cvt<BF16>(*reinterpret_cast<const u32x4*>(wb + e * 2));
+      float sq[8];
+      Acc acc;
+      acc.abs = 0.0;
+      acc.xp = nullptr;
+      acc.sq = sq;
+      quant8_slow<FMT, SEL_STATS_ONLY>(p, raw, sp, 0, acc);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r[i] = k == 0 ? sq[i] : r[i] + sq[i];
+    }
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  };
+  auto wave_sync = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+  for (int64_t c = (int64_t)p.bx * 4 + wv; c < nchunks; c += (int64_t)p.gx * 4) {
+    float total = 0.f;
+    if (c < nfull) {
+      leaf_sum[wv][lane] = leaf(c * 8192 + (int64_t)lane * 128, 16);
+      wave_sync();
+      // the perfect tree over the 64 leaves: neighbours first, the left operand on the left
+      for (int w2 = 1; w2 < 64; w2 <<= 1) {
+        if ((lane & (2 * w2 - 1)) == 0) leaf_sum[wv][lane] = leaf_sum[wv][lane] + leaf_sum[wv][lane + w2];
+        wave_sync();
+      }
+      total = leaf_sum[wv][0];
+    } else {
+      for (int l = lane; l < b.np.nleaves; l += 64)
+        leaf_sum[wv][l] = leaf(c * 8192 + (int64_t)leaf_off[l] * 8, b.np.len[l]);
+      wave_sync();
+      if (lane == 0) total = numpy_run_prog<float>(b.np.ops, b.np.nops, &leaf_sum[wv][0]);
+    }
+    if (lane == 0) cs[c] = total;
+    wave_sync();  // (the leaf sums are consumed before the next chunk's are written)
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // SC_TENSOR: group_size == -1.  k_tensor_reduce leaves the tensor's absmax / min / max in tred[];
 // k_quant_tensor then treats the flat tensor as one segment whose parameters every lane derives itself.
@@ -2100,6 +2173,24 @@ __global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
   if (threadIdx.x == 0) *b.out[blockIdx.x] = total / (double)b.n;
 }
 
+// The chunk sums of k_tensor_mse_numpy added in order in float32 (numpy's reduction adds each chunk's pairwise sum to
+// its running result), then np.mean's division: float32(float64(sum) / n).  One workgroup: the sums are staged
+// through LDS 1024 at a time, thread 0 adds.
+__global__ __launch_bounds__(256) void k_tensor_mse_finish(const float* cs, int64_t nchunks, int64_t n, float* out) {
+  __shared__ float buf[1024];
+  float total = 0.f;
+  for (int64_t base = 0; base < nchunks; base += 1024) {
+    for (int j = threadIdx.x; j < 1024; j += 256) buf[j] = base + j < nchunks ? cs[base + j] : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = nchunks - base < 1024 ? (int)(nchunks - base) : 1024;
+      for (int j = 0; j < m; ++j) total = (base == 0 && j == 0) ? buf[0] : total + buf[j];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)((double)total / (double)n);
+}
+
 // The record rows of one pass of a sweep (numel, sse, sum |err|, mean squared error, P99 of the per-vector list, 0),
 // scattered into the order of the caller's weights: row perm[i] from the i-th tensor's totals and percentile.
 __global__ __launch_bounds__(256) void k_sweep_records(const double* totals, const double* p99, const double* numel,
@@ -2220,7 +2311,9 @@ static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, co
 template <int FMT, bool BF16>
 static void launch_stats(int scope, int nv, int team_log2, dim3 grid, hipStream_t st, const QuantBatch& p) {
 #define MQ_STATS_ROW(NV, WPR) hipLaunchKernelGGL((k_stats_row<FMT, BF16, NV, WPR>), grid, dim3(256), 0, st, p)
-  if (scope == SC_STATS_ROWNP) {
+  if (scope == SC_TENSOR_NP) {
+    hipLaunchKernelGGL((k_tensor_mse_numpy<FMT, BF16>), grid, dim3(256), 0, st, p);
+  } else if (scope == SC_STATS_ROWNP) {
     hipLaunchKernelGGL((k_rows_numpy<FMT, BF16>), grid, dim3(256), 0, st, p);
   } else if (scope == SC_STATS_GROUP && p.common.seg_exact) {  // (the host admits team_log2 <= 2 only)
     switch (team_log2) {
@@ -2871,6 +2964,63 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
   MQ_HIP(hipGetLastError());
   if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
   hipLaunchKernelGGL(k_finalize_sweep, dim3((unsigned)count), dim3(256), 0, st, b);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+extern "C" size_t mq_tensor_mse_numpy_workspace_bytes(int64_t rows, int64_t cols) {
+  const int64_t n = rows * cols;
+  return kWsHeader + (size_t)((n + 8191) / 8192 < 1 ? 1 : (n + 8191) / 8192) * sizeof(float);
+}
+extern "C" int mq_tensor_mse_numpy(const void* w, int32_t w_dtype, int64_t rows, int64_t cols, const mq_quant_cfg* cfg,
+                                   const void* scale, const void* zero_point, float* mse_out, void* workspace,
+                                   size_t workspace_bytes, void* hip_stream) {
+  if (!w || !cfg || !scale || !mse_out || rows < 1 || cols < 1) return MQ_ERR_ARG;
+  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16) return w_dtype == MQ_F32 ? MQ_ERR_UNSUPPORTED : MQ_ERR_ARG;
+  const bool is_lut = cfg->format == MQ_LUT_FP || cfg->format == MQ_LUT_FP_SUB;
+  if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && !is_lut) return MQ_ERR_ARG;
+  if (!is_lut && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+  if (cfg->f32_math) return MQ_ERR_UNSUPPORTED;
+  if (cfg->format == MQ_INT_ASYM && !zero_point) return MQ_ERR_ARG;
+  if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
+  const int64_t n = rows * cols;
+  const int64_t L = cfg->group_size == -1 ? n : (cfg->group_size <= 0 ? cols : cfg->group_size);
+  if (L % 8 || !aligned(w, 16)) return MQ_ERR_UNSUPPORTED;  // a 16-byte vector must lie inside one segment
+  if (!aligned(scale, 2) || !aligned(zero_point, 2) || !aligned(mse_out, 4) || !aligned(workspace, 16)) return MQ_ERR_ALIGN;
+  if (!workspace || workspace_bytes < mq_tensor_mse_numpy_workspace_bytes(rows, cols)) return MQ_ERR_WORKSPACE;
+  QuantBatch b = {};
+  QuantParams& p = b.common;
+  p.in_dtype = w_dtype;
+  p.n = n;
+  p.L = L;
+  p.nseg = n / L;
+  p.vecs_per_seg = (int32_t)(L / 8 > INT32_MAX ? INT32_MAX : L / 8);
+  const int fmt = cfg->format;
+  if (fmt == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
+  else if (fmt == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
+  else if (!lut_consts(cfg, false, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
+  p.rqmax = 1.0f / p.qmax;
+  p.qmax_recip_ok = recip_ok_cached(p.qmax);
+  p.need_err = 1;
+  p.sel_mode = SEL_FEED_OFF;
+  p.tred = static_cast<const uint32_t*>(workspace);
+  b.ws_stride = 0;
+  b.item[0].w = w;
+  b.item[0].scale = static_cast<uint16_t*>(const_cast<void*>(scale));
+  b.item[0].zp = static_cast<uint16_t*>(const_cast<void*>(zero_point));
+  if (n % 8192 && !numpy_prog(n % 8192, &b.np)) return MQ_ERR_UNSUPPORTED;
+  const int64_t nchunks = (n + 8191) / 8192, wb = (nchunks + 3) / 4;
+  const dim3 grid((unsigned)(wb < grid_cap() ? wb : grid_cap()));
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  switch (fmt) {
+    case MQ_INT_SYM: mq_launch_fmt1(SEL_STATS_ONLY, SC_TENSOR_NP, 4, 256, 0, grid, 0, st, b); break;
+    case MQ_INT_ASYM: mq_launch_fmt2(SEL_STATS_ONLY, SC_TENSOR_NP, 4, 256, 0, grid, 0, st, b); break;
+    case MQ_LUT_FP: mq_launch_fmt3(SEL_STATS_ONLY, SC_TENSOR_NP, 4, 256, 0, grid, 0, st, b); break;
+    default: mq_launch_fmt4(SEL_STATS_ONLY, SC_TENSOR_NP, 4, 256, 0, grid, 0, st, b); break;
+  }
+  MQ_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_tensor_mse_finish, dim3(1), dim3(256), 0, st,
+                     reinterpret_cast<const float*>(static_cast<const char*>(workspace) + kWsHeader), nchunks, n, mse_out);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }

@@ -233,6 +233,10 @@ def bind_batch():
                                         ctypes.POINTER(_lib.QuantCfg), vp, sz, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         L_.mq_sweep_run.restype = ctypes.c_int
         L_.mq_sweep_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), i32, vp, sz, vp]
+        L_.mq_tensor_mse_numpy_workspace_bytes.restype = sz
+        L_.mq_tensor_mse_numpy_workspace_bytes.argtypes = [i64, i64]
+        L_.mq_tensor_mse_numpy.restype = ctypes.c_int
+        L_.mq_tensor_mse_numpy.argtypes = [vp, i32, i64, i64, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp, vp, sz, vp]
         L_.mq_list_mean_numpy.restype = ctypes.c_int
         L_.mq_list_mean_numpy.argtypes = [ctypes.POINTER(vp), i32, i64, ctypes.POINTER(vp), vp]
         L_.mq_sweep_records.restype = ctypes.c_int

@@ -88,7 +88,8 @@ def layer_record(w: torch.Tensor, datatype: str, bits: int, group_size, form: st
 
 @torch.no_grad()
 def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool = True, pct: float = 99.0,
-                  max_err_bytes: int = 8 << 30, return_vecs: bool = False, numpy_order: bool = False):
+                  max_err_bytes: int = 8 << 30, return_vecs: bool = False, numpy_order: bool = False,
+                  return_mse_tensor: bool = False):
     """layer_record(form="single") for every weight of a model at once: float64 [len(weights), len(RECORD_FIELDS)]
     on the device, nothing synchronised.
 
@@ -127,16 +128,34 @@ def model_records(weights, datatype: str, bits: int, group_size, abs_p99: bool =
         raise ValueError("numpy_order is a statistics-only mode: pass abs_p99=False")
     state = _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes, numpy_order)
     out = _finish_pass(weights, state, abs_p99, pct)
+    mse_tensor = None
     if numpy_order:   # mse_rep in numpy's bits: the float64 mean of the list, in numpy's summation order
         vecs = [v for r in state[1] for v in r.seg_mse.unbind(0)]
         rep = numpy_list_means(vecs)
         out[torch.as_tensor(state[0], device=out.device), 3] = rep
+    if return_mse_tensor:
+        # mse_tensor = float(np.mean((a32 - b32) ** 2)): sse / numel to 1e-6, or -- numpy_order -- numpy's bits
+        mse_tensor = out[:, 1] / out[:, 0]
+        if numpy_order:
+            from .fused import make_cfg
+            cfg = make_cfg(fmt, bits, group_size, table)
+            m32 = torch.empty(len(weights), dtype=torch.float32, device=dev)
+            k = 0
+            for r in state[1]:
+                for j in range(r.scale.shape[0]):
+                    i = state[0][k]
+                    tensor_mse_numpy(weights[i], cfg, r.scale[j], None if r.zero_point is None else r.zero_point[j], m32[i])
+                    k += 1
+            mse_tensor = m32.double()
+    extra = []
     if return_vecs:
         vec_rows, keep = state[0], state[1]
         vecs = [v for r in keep for v in r.seg_mse.unbind(0)]
         order = {i: k for k, i in enumerate(vec_rows)}
-        return out, [vecs[order[i]] for i in range(len(weights))]
-    return out
+        extra.append([vecs[order[i]] for i in range(len(weights))])
+    if return_mse_tensor:
+        extra.append(mse_tensor)
+    return (out, *extra) if extra else out
 
 
 def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_bytes, numpy_order=False):
@@ -156,7 +175,7 @@ def _launch_pass(weights, fmt, table, bits, group_size, abs_p99, pct, max_err_by
             sel = idx[lo:lo + chunk]
             # (every chunk keeps its own result: the lists are read by the selection after the last launch)
             res = quantize_batch([weights[i] for i in sel], fmt, bits, group_size, table, deq=False, codes=False,
-                                 scale=False, abs_err=torch.float32 if abs_p99 else None,
+                                 scale=bool(numpy_order), abs_err=torch.float32 if abs_p99 else None,
                                  seg_mse="numpy" if numpy_order else True, totals=True,
                                  p99=pct if abs_p99 else None)
             tots.append(res.totals)
@@ -213,6 +232,22 @@ def numpy_list_means(lists, stream=None) -> torch.Tensor:
     return out
 
 
+def tensor_mse_numpy(w: torch.Tensor, cfg, scale: torch.Tensor, zero_point: Optional[torch.Tensor], out: torch.Tensor,
+                     stream=None) -> None:
+    """out[()] (float32, device) = np.mean((a32 - b32) ** 2) over the whole weight, bit for bit: compute_mse of
+    quant_error_multi_weight.py:55-58 in numpy's summation order (mq_tensor_mse_numpy).  cfg: the mq_quant_cfg of the
+    pass; scale / zero_point: the float16 segment parameters a statistics pass wrote for this weight."""
+    from .fused import _DTYPES, bind_batch, workspace
+    L = bind_batch()
+    K, C = w.shape
+    st = stream or torch.cuda.current_stream(w.device)
+    with torch.cuda.stream(st):
+        ws, _ = workspace(w.device, L.mq_tensor_mse_numpy_workspace_bytes(K, C))
+    _lib.check(L.mq_tensor_mse_numpy(w.data_ptr(), _DTYPES[w.dtype], K, C, cfg, scale.data_ptr(),
+                                     zero_point.data_ptr() if zero_point is not None else None, out.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), st.cuda_stream))
+
+
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -232,7 +267,8 @@ class SweepPlan:
     the chip idle -- run on a second HIP stream while the current stream already streams the weights for pass
     k + 1; the streams are joined before run() returns, so the result is ordered on the current stream.
     numpy_order: as for model_records (per-channel passes and group sizes other than 32 / 64 / 128 then go through the
-    batched launches and the slower wave-per-segment kernel)."""
+    batched launches and the slower wave-per-segment kernel); mse_rep and mse_p99 of the records and the tensor means
+    in `mse_tensor` [len(passes), len(weights)] then have the reference's bits."""
 
     def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True):
         import ctypes
@@ -258,6 +294,8 @@ class SweepPlan:
         self.numel = torch.tensor([float(self.weights[i].numel()) for i in self.order], dtype=torch.float64, device=dev)
         self.perm = torch.tensor(self.order, dtype=torch.int64, device=dev)
         self.records = torch.zeros(len(self.passes), nl, len(RECORD_FIELDS), dtype=torch.float64, device=dev)
+        # numpy_order: float64 [len(passes), len(weights)], the scripts' mse_tensor bit for bit (filled by run())
+        self.mse_tensor = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev) if numpy_order else None
         self.ws_bytes = 0
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
@@ -285,6 +323,9 @@ class SweepPlan:
             for pos, i in enumerate(self.order):
                 lists[i] = mse[offs[pos]:offs[pos] + ns[pos]]
             ptrs = [mse.data_ptr() + o * 4 for o in offs]
+            # numpy_order: the segments' scales (and zero-points) are kept -- the tensor mean in numpy's order reads them
+            scl = torch.empty(total, dtype=torch.float16, device=dev) if numpy_order else None
+            zpt = torch.empty(total, dtype=torch.float16, device=dev) if numpy_order and fmt == _lib.INT_ASYM else None
 
             def make_items(poss):
                 items = (_QuantItem * len(poss))()
@@ -295,6 +336,10 @@ class SweepPlan:
                     o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
                     o.seg_sse = ptrs[pos]
                     o.totals = totals.data_ptr() + pos * 16
+                    if scl is not None:
+                        o.scale = scl.data_ptr() + offs[pos] * 2
+                    if zpt is not None:
+                        o.zero_point = zpt.data_ptr() + offs[pos] * 2
                 return items
 
             # Launches.  Layers whose segments have one length go through ONE launch whatever their shapes (the
@@ -332,7 +377,11 @@ class SweepPlan:
                         self.ws_bytes = max(self.ws_bytes,
                                             L.mq_quantize_batch_workspace_bytes(len(sel), K, C, ctypes.byref(cfg)))
                         launches.append(("batch", make_items(sel), len(sel), _DTYPES[dtype], K, C))
-            self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse,
+            params = None
+            if numpy_order:
+                params = [(scl[offs[pos]:offs[pos] + ns[pos]],
+                           None if zpt is None else zpt[offs[pos]:offs[pos] + ns[pos]]) for pos in range(nl)]
+            self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
                                   ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns)))
         self.sel_ws_bytes = self.L.mq_percentile_batch_workspace_bytes(min(nl, 64))
 
@@ -387,8 +436,14 @@ class SweepPlan:
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
                                                   self.perm.data_ptr(), nl, self.records[k].data_ptr(),
                                                   side.cuda_stream))
-                    if self.numpy_order:   # mse_rep in numpy's bits (the lists in the order of `weights`)
+                    if self.numpy_order:   # mse_rep in numpy's bits (the lists in the order of `weights`) ...
                         self.records[k][:, 3] = numpy_list_means(ps["lists"], side)
+                        # ... and mse_tensor: numpy's float32 summation over each flattened weight
+                        m32 = torch.empty(nl, dtype=torch.float32, device=dev)
+                        for pos, i in enumerate(self.order):
+                            sc, zp = ps["params"][pos]
+                            tensor_mse_numpy(self.weights[i], cfg, sc, zp, m32[pos], side)
+                        self.mse_tensor[k].index_copy_(0, self.perm, m32.double())
             self._pending = (main, side)
 
     @torch.no_grad()
@@ -465,13 +520,17 @@ def compare_onnx_single(baseline_model: str, quant_models: Iterable[str], initia
     return rows, hists
 
 
-def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size) -> List[Dict]:
-    """Device records -> the CSV rows of quant_error_multi_weight.py:142-151 (one host copy)."""
+def rows_from_records(names: Iterable[str], records: torch.Tensor, datatype: str, bits: int, group_size,
+                      mse_tensor: Optional[torch.Tensor] = None) -> List[Dict]:
+    """Device records -> the CSV rows of quant_error_multi_weight.py:142-151 (one host copy).  mse_tensor: the
+    tensor means when they were computed apart (numpy_order: model_records(return_mse_tensor=True),
+    SweepPlan.mse_tensor), else sse / numel."""
     host = records.cpu().tolist()
+    mt = mse_tensor.cpu().tolist() if mse_tensor is not None else None
     rows = []
-    for name, r in zip(names, host):
+    for k, (name, r) in enumerate(zip(names, host)):
         rows.append({"initializer": name, "datatype": datatype, "granularity": granularity(group_size),
-                     "bits": bits or "", "mse_tensor": r[1] / r[0] if r[0] else float("nan"),
+                     "bits": bits or "", "mse_tensor": mt[k] if mt is not None else (r[1] / r[0] if r[0] else float("nan")),
                      "mse_rep": r[3], "mse_p99": r[4], "abs_sum": r[2], "abs_p99": r[5]})
     return rows
 

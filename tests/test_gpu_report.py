@@ -106,13 +106,18 @@ def test_model_records_vs_oracle(oracle):
                 assert rec[i, 4] == np.percentile(v.astype(np.float64), 99)
             # numpy_order: the list entries have numpy's bits, so mse_p99 is the reference's value bit for bit --
             # per-group and per-channel (rows go through the wave-per-segment kernel)
-            for make in (lambda: report.model_records(ws, datatype, 8, gs, abs_p99=False, numpy_order=True),
-                         lambda: report.SweepPlan(ws, [(datatype, 8, gs)], numpy_order=True).run()[0]):
-                ex = make().cpu().numpy()
+            def by_plan():
+                plan = report.SweepPlan(ws, [(datatype, 8, gs)], numpy_order=True)
+                return plan.run()[0], plan.mse_tensor[0]
+            for make in (lambda: report.model_records(ws, datatype, 8, gs, abs_p99=False, numpy_order=True,
+                                                      return_mse_tensor=True), by_plan):
+                ex, mt = make()
+                ex, mt = ex.cpu().numpy(), mt.cpu().numpy()
                 for i, w in enumerate(w16):
                     ce, _ = _np_record(oracle, w, datatype, gs, "single")
                     assert ex[i, 4] == ce["mse_p99"], (datatype, gs, i)
                     assert ex[i, 3] == ce["mse_rep"], (datatype, gs, i)   # float(vec.mean()) in numpy's order
+                    assert mt[i] == ce["mse_tensor"], (datatype, gs, i)   # float(np.mean((a32 - b32) ** 2))
                     assert abs(ex[i, 1] / ex[i, 0] - ce["mse_tensor"]) <= 1e-6 * ce["mse_tensor"]
     with pytest.raises(ValueError):   # float32 weights: not offered in numpy's order
         report.model_records([w.float() for w in ws], "int8", 8, None, abs_p99=False, numpy_order=True)
