@@ -2,7 +2,8 @@
 oracle; tests/fuzz_quant.py: the general kernels, every output, against the CPU oracle; tests/fuzz_tables.py: the
 explicit-list formats, MX and the datatype search against the CPU oracle; tests/fuzz_select.py:
 percentile selection against numpy; tests/fuzz_errors.py: the error half against the scripts' numpy arithmetic;
-tests/fuzz_sweep.py: SweepPlan against model_records against layer_record) with fixed seeds, and the cases those runs have found.  Longer runs:
+tests/fuzz_sweep.py: SweepPlan against model_records against layer_record; tests/fuzz_numpy_order.py: the numpy-order
+list entries, list means and tensor means against numpy) with fixed seeds, and the cases those runs have found.  Longer runs:
 `python tests/fuzz_stats.py 90 1`, `python tests/fuzz_quant.py 100 1`, `python tests/fuzz_select.py 120 1`."""
 import pytest
 
@@ -12,6 +13,11 @@ pytestmark = pytest.mark.gpu
 def test_statistics_kernels_random_cases(oracle):
     import fuzz_stats
     assert fuzz_stats.run(6.0, 12345) > 50
+
+
+def test_numpy_order_modes_random_cases(oracle):
+    import fuzz_numpy_order
+    assert fuzz_numpy_order.run(6.0, 2024) > 20
 
 
 def test_percentile_selection_random_cases():
