@@ -182,8 +182,7 @@ int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t 
  * each chunk pairwise down to leaves of at most 128 elements -- and divided by the count in float64.  The chunks
  * cross rows and groups, so the segments' parameters are inputs: scale (and zero_point for MQ_INT_ASYM), float16
  * [nseg], as a statistics pass of mq_quantize / mq_sweep_run wrote them for this weight and configuration.
- * float16 / bfloat16 weights, 16-byte aligned, segment length a multiple of 8, at most 2^29 elements
- * (MQ_ERR_UNSUPPORTED otherwise).  workspace: mq_tensor_mse_numpy_workspace_bytes(rows, cols).  Two launches; a
+ * float16 / bfloat16 weights, 16-byte aligned, segment length a multiple of 8 (MQ_ERR_UNSUPPORTED otherwise).  workspace: mq_tensor_mse_numpy_workspace_bytes(rows, cols).  Two launches; a
  * correctness mode for report.*(numpy_order=True) -- every element takes the per-element routine -- not a bandwidth
  * path.
  */
