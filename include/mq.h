@@ -202,6 +202,19 @@ int mq_tensor_mse_numpy(const void* w, int32_t w_dtype, int64_t rows, int64_t co
 int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, double* const* out, void* hip_stream);
 
 /*
+ * np.mean of slices of a float32 array in numpy's bits (float32 summation in numpy's order, the sum divided by the
+ * count in float64 and rounded to float32): compute_mse on the slices the analysis scripts take from the squared-
+ * error array -- a column a[:, j] or a block of gs columns a[:, g*gs:(g+1)*gs] (quant_error_multi_weight.py:67-78),
+ * a row or a run of a row (quant_error_single_weight.py:56-71), the whole array (:55-58).  Slice i holds n values:
+ * value t is firsts[i][(t / run) * stride + t % run] -- runs of `run` contiguous values, `stride` elements apart, the
+ * order in which numpy walks the slice (a column: run 1, stride = columns; a block: run gs; contiguous: run = n).
+ * firsts / out: HOST arrays of device pointers (float32; one float32 result each).  One workgroup per slice, 64
+ * slices per launch: a correctness mode for error_metrics.compute_errors(numpy_order=True).
+ */
+int mq_slice_mean_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
+                            float* const* out, void* hip_stream);
+
+/*
  * The report rows of one pass (the CSV rows of quant_error_multi_weight.py:142-151 before formatting): for tensor i
  * of `count`, records[perm[i]][0..5] = numel[i], totals[i][0] (sum of squared errors), totals[i][1] (sum of |error|),
  * totals[i][0] / numel[i] (mse_tensor = mse_rep, IEEE float64 division), p99[i] (mse_p99; NaN when the mean is NaN,

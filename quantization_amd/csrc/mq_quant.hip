@@ -2124,30 +2124,43 @@ struct ListProg {
 #define MQ_LIST_BATCH 64
 struct ListBatch {
   const float* x[MQ_LIST_BATCH];
-  double* out[MQ_LIST_BATCH];
-  int64_t n;  // every list of a launch has this length
+  void* out[MQ_LIST_BATCH];
+  int64_t n;       // every list of a launch has this length
+  int64_t run, S;  // element t of a list is x[(t / run) * S + t % run]: runs of `run` contiguous values, S elements
+                   // apart (a contiguous list: run = n; a column of a row-major matrix: run = 1, S = columns; a block
+                   // of gs columns in numpy's C order: run = gs, S = columns)
   ListProg full, tail;
 };
-__device__ __forceinline__ double numpy_leaf_f64(const float* a, int n) {
+// one leaf (n <= 128 values, the first at list position t0) in accumulator type Acc
+template <typename Acc>
+__device__ __forceinline__ Acc numpy_leaf(const ListBatch& b, const float* x, int64_t t0, int n) {
+  auto at = [&](int i) __attribute__((always_inline)) {
+    const int64_t t = t0 + i;
+    return (Acc)(b.run == b.n ? x[t] : x[(t / b.run) * b.S + t % b.run]);
+  };
   if (n < 8) {
-    double res = 0.0;
-    for (int i = 0; i < n; ++i) res += (double)a[i];
+    Acc res = (Acc)0;
+    for (int i = 0; i < n; ++i) res += at(i);
     return res;
   }
-  double r[8];
+  Acc r[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (double)a[j];
+  for (int j = 0; j < 8; ++j) r[j] = at(j);
   int i = 8;
   for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] += (double)a[i + j];
+    for (int j = 0; j < 8; ++j) r[j] += at(i + j);
   }
-  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-  for (; i < n; ++i) res += (double)a[i];
+  Acc res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += at(i);
   return res;
 }
+// Acc = double: the float64 mean of float32 values (vec.mean() of the float64 array holding them), out: double.
+// Acc = float: np.mean of a float32 array -- the float32 sum divided by the count in float64, rounded to float32
+// (compute_mse on a slice) -- out: float.
+template <typename Acc>
 __global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
-  __shared__ double leaf[128];
+  __shared__ Acc leaf[128];
   __shared__ uint16_t off_full[128], off_tail[128];
   const float* x = b.x[blockIdx.x];
   if (threadIdx.x == 0) {
@@ -2157,20 +2170,23 @@ __global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
     for (int i = 0; i < b.tail.nleaves; ++i) { off_tail[i] = (uint16_t)o; o += b.tail.len[i]; }
   }
   __syncthreads();
-  double total = 0.0;  // (thread 0's; 0 + x = x: the first chunk's sum as it is)
+  Acc total = (Acc)0;  // (thread 0's; the first chunk's sum as it is)
   for (int64_t c0 = 0; c0 < b.n; c0 += 8192) {
     const bool is_tail = b.n - c0 < 8192;
     const ListProg& pr = is_tail ? b.tail : b.full;
     const uint16_t* off = is_tail ? off_tail : off_full;
-    if ((int)threadIdx.x < pr.nleaves) leaf[threadIdx.x] = numpy_leaf_f64(x + c0 + off[threadIdx.x], pr.len[threadIdx.x]);
+    if ((int)threadIdx.x < pr.nleaves) leaf[threadIdx.x] = numpy_leaf<Acc>(b, x, c0 + off[threadIdx.x], pr.len[threadIdx.x]);
     __syncthreads();
     if (threadIdx.x == 0) {
-      const double c = numpy_run_prog<double>(pr.ops, pr.nops, &leaf[0]);
+      const Acc c = numpy_run_prog<Acc>(pr.ops, pr.nops, &leaf[0]);
       total = c0 == 0 ? c : total + c;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *b.out[blockIdx.x] = total / (double)b.n;
+  if (threadIdx.x == 0) {
+    if constexpr (sizeof(Acc) == 8) *static_cast<double*>(b.out[blockIdx.x]) = total / (double)b.n;
+    else *static_cast<float*>(b.out[blockIdx.x]) = (float)((double)total / (double)b.n);
+  }
 }
 
 // The chunk sums of k_tensor_mse_numpy added in order in float32 (numpy's reduction adds each chunk's pairwise sum to
@@ -3025,24 +3041,38 @@ extern "C" int mq_tensor_mse_numpy(const void* w, int32_t w_dtype, int64_t rows,
   return MQ_OK;
 }
 
-extern "C" int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, double* const* out,
-                                  void* hip_stream) {
-  if (count < 0 || n < 1 || (count > 0 && (!lists || !out))) return MQ_ERR_ARG;
+static int list_mean_launch(const void* const* lists, int32_t count, int64_t n, int64_t run, int64_t stride,
+                            void* const* out, bool f64, hipStream_t st) {
+  if (count < 0 || n < 1 || run < 1 || (count > 0 && (!lists || !out))) return MQ_ERR_ARG;
+  if (run > n || n % run || (run != n && stride < run)) return MQ_ERR_ARG;
   ListBatch b = {};
   b.n = n;
+  b.run = run;
+  b.S = stride;
   if (!list_prog(n < 8192 ? 0 : 8192, &b.full) || !list_prog(n % 8192, &b.tail)) return MQ_ERR_UNSUPPORTED;
   for (int32_t done = 0; done < count; done += MQ_LIST_BATCH) {
     const int32_t c = count - done < MQ_LIST_BATCH ? count - done : MQ_LIST_BATCH;
     for (int32_t i = 0; i < c; ++i) {
       if (!lists[done + i] || !out[done + i]) return MQ_ERR_ARG;
-      if (!aligned(lists[done + i], 4) || !aligned(out[done + i], 8)) return MQ_ERR_ALIGN;
+      if (!aligned(lists[done + i], 4) || !aligned(out[done + i], f64 ? 8 : 4)) return MQ_ERR_ALIGN;
       b.x[i] = static_cast<const float*>(lists[done + i]);
       b.out[i] = out[done + i];
     }
-    hipLaunchKernelGGL(k_list_mean_numpy, dim3((unsigned)c), dim3(128), 0, static_cast<hipStream_t>(hip_stream), b);
+    if (f64) hipLaunchKernelGGL(k_list_mean_numpy<double>, dim3((unsigned)c), dim3(128), 0, st, b);
+    else hipLaunchKernelGGL(k_list_mean_numpy<float>, dim3((unsigned)c), dim3(128), 0, st, b);
     MQ_HIP(hipGetLastError());
   }
   return MQ_OK;
+}
+extern "C" int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, double* const* out,
+                                  void* hip_stream) {
+  return list_mean_launch(lists, count, n, n, n, reinterpret_cast<void* const*>(out), true,
+                          static_cast<hipStream_t>(hip_stream));
+}
+extern "C" int mq_slice_mean_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
+                                       float* const* out, void* hip_stream) {
+  return list_mean_launch(firsts, count, n, run, stride, reinterpret_cast<void* const*>(out), false,
+                          static_cast<hipStream_t>(hip_stream));
 }
 
 extern "C" int mq_sweep_records(const double* totals, const double* p99, const double* numel, const int64_t* perm,

@@ -274,16 +274,68 @@ def compute_mse(a, b) -> float:
     return float(st["totals"][0].item() / n) if n else float("nan")
 
 
-def compute_errors(a, b, grouping: str, gs: Optional[int], form: str = "multi", keep_per_vec: bool = False):
+def slice_means_numpy(sq: torch.Tensor, offsets: Sequence[int], n: int, run: int, stride: int) -> torch.Tensor:
+    """np.mean of slices of the contiguous float32 tensor `sq`, bit for bit (mq_slice_mean_numpy_f32): slice i starts
+    at element offsets[i] and holds n values in runs of `run` contiguous ones, `stride` elements apart -- a column of
+    a [K, C] matrix: n = K, run = 1, stride = C; a block of gs columns: n = K * gs, run = gs; a row: run = n = C.
+    -> float32 [len(offsets)]."""
+    from .fused import bind_batch
+    L = bind_batch()
+    if sq.dtype != torch.float32 or not sq.is_contiguous():
+        raise ValueError("slice_means_numpy takes a contiguous float32 tensor")
+    out = torch.empty(len(offsets), dtype=torch.float32, device=sq.device)
+    base, ob = sq.data_ptr(), out.data_ptr()
+    firsts = (ctypes.c_void_p * len(offsets))(*[base + 4 * int(o) for o in offsets])
+    outs = (ctypes.c_void_p * len(offsets))(*[ob + 4 * i for i in range(len(offsets))])
+    _lib.check(L.mq_slice_mean_numpy_f32(firsts, len(offsets), n, run, stride, outs,
+                                         torch.cuda.current_stream(sq.device).cuda_stream))
+    return out
+
+
+def _compute_errors_numpy(a, b, grouping, gs, form, keep_per_vec):
+    """compute_errors in numpy's bits: the float32 squared errors as the scripts form them, every mean summed in
+    numpy's order (slice_means_numpy; the list's float64 mean: report.numpy_list_means)."""
+    from .report import numpy_list_means
+    d = a.float() - b.float()            # proto_to_array: float32 (quant_error_multi_weight.py:35-38)
+    sq = (d * d).contiguous()            # (a32 - b32) ** 2: float32 products
+    n = sq.numel()
+    result = {"mse_tensor": float(slice_means_numpy(sq.reshape(-1), [0], n, n, n)[0].item())}
+    if a.dim() == 2 and grouping in ("per-channel", "per-group"):
+        K, C = a.shape
+        if grouping == "per-group":
+            assert gs and C % gs == 0, "group size mismatch"
+        if form == "multi":     # columns / column blocks, walked in numpy's C order
+            if grouping == "per-channel":
+                vec = slice_means_numpy(sq, range(C), K, 1, C)
+            else:
+                vec = slice_means_numpy(sq, range(0, C, gs), K * gs, gs, C)
+        else:                   # rows / (row, group) runs: contiguous
+            L = C if grouping == "per-channel" else gs
+            vec = slice_means_numpy(sq, range(0, K * C, L), L, L, L)
+        result["mse_rep"] = float(numpy_list_means([vec])[0].item())
+        result["mse_p99"] = float(percentile(vec, 99, wide=True).item())
+        if keep_per_vec or form == "single":
+            result["per_vec"] = vec
+    return result
+
+
+def compute_errors(a, b, grouping: str, gs: Optional[int], form: str = "multi", keep_per_vec: bool = False,
+                   numpy_order: bool = False):
     """mse_tensor, and for 2-D inputs the per-vector MSE list's mean (mse_rep) and P99 (mse_p99).
 
     form="multi":  vectors are COLUMNS (per-channel) or column blocks of gs columns (per-group)
                    -- quant_error_multi_weight.py:61-87
     form="single": vectors are ROWS (per-channel) or (row, group) runs in row-major order (per-group)
                    -- quant_error_single_weight.py:50-79 (without its plt.hist side effect)
+    numpy_order:   every mean is summed in numpy's order (its 8192-element chunks and pairwise split, over the slice
+                   in the order numpy walks it) and the three numbers have the scripts' BITS; a correctness mode that
+                   materialises the float32 squared errors and spends one workgroup per vector.  Default: float64
+                   sums in one pass over the two tensors, equal to the scripts' numbers to 1e-6.
     """
     a = require_device(a)
     b = require_device(b)
+    if numpy_order:
+        return _compute_errors_numpy(a, b, grouping, gs, form, keep_per_vec)
     K, C = (a.shape if a.dim() == 2 else (0, 0))
     per_vec = None
     if a.dim() == 2 and grouping in ("per-channel", "per-group"):

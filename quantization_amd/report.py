@@ -467,11 +467,13 @@ def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = Non
     return (out, plan.lists(vecs_of)) if vecs_of is not None else out
 
 
-def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", device=None) -> List[Dict]:
+def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", device=None,
+                 numpy_order: bool = False) -> List[Dict]:
     """main() of MSE&P99/quant_error_multi_weight.py:119-164 on two ONNX files, without the `onnx` package and
     with the arithmetic on the device: for every MatMul / Gemm weight of the baseline model that the quantized
     model also holds, float32 cast, tensor MSE, per-vector MSE list (form="multi": columns / column blocks as
     that script; form="single": rows / (row, group) as quant_error_single_weight.py), its mean and P99.
+    numpy_order: every mean in numpy's summation order -- the script's numbers bit for bit (compute_errors).
     Returns the CSV rows (write them with write_csv)."""
     from .error_metrics import compute_errors
     from .onnx_io import OnnxWeights
@@ -485,7 +487,7 @@ def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", dev
                 continue
             a = base.tensor(name, device).float()   # proto_to_array: everything becomes float32
             b = quant.tensor(name, device).float()
-            stats = compute_errors(a, b, grouping, gs, form=form)
+            stats = compute_errors(a, b, grouping, gs, form=form, numpy_order=numpy_order)
             rows.append({"initializer": name, "datatype": dtype, "granularity": grouping, "bits": bits or "",
                          "mse_tensor": stats["mse_tensor"], "mse_rep": stats.get("mse_rep", ""),
                          "mse_p99": stats.get("mse_p99", "")})
@@ -493,11 +495,12 @@ def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", dev
 
 
 def compare_onnx_single(baseline_model: str, quant_models: Iterable[str], initializer: str, bins: int = 50,
-                        device=None):
+                        device=None, numpy_order: bool = False):
     """main() of MSE&P99/quant_error_single_weight.py:85-140 for one initializer of the baseline model and several
     quantized models: one CSV row per quantized model (tensor MSE; mean and P99 of the per-row / per-(row, group)
     MSE list) and, in place of the script's plt.hist(vec, bins=50) calls (:118-124), each list's np.histogram
-    counts and edges computed on the device.  -> (rows, {label: (counts int64 tensor, edges ndarray)})"""
+    counts and edges computed on the device.  numpy_order: as for compare_onnx.
+    -> (rows, {label: (counts int64 tensor, edges ndarray)})"""
     from .error_metrics import compute_errors, histogram
     from .onnx_io import OnnxWeights
     rows, hists = [], {}
@@ -511,7 +514,7 @@ def compare_onnx_single(baseline_model: str, quant_models: Iterable[str], initia
             if initializer not in set(quant.names()):
                 continue                                           # the script warns and skips (:101-103)
             b = quant.tensor(initializer, device).float()
-        stats = compute_errors(a, b, grouping, gs, form="single", keep_per_vec=True)
+        stats = compute_errors(a, b, grouping, gs, form="single", keep_per_vec=True, numpy_order=numpy_order)
         rows.append({"datatype": dtype, "granularity": grouping, "bits": bits or "",
                      "mse_tensor": stats["mse_tensor"], "mse_rep": stats.get("mse_rep", ""),
                      "mse_p99": stats.get("mse_p99", "")})

@@ -97,6 +97,13 @@ def test_known_answers(em, oracle):
                               (multi["mse_rep"], e["multi"]["mse_rep"]), (multi["mse_p99"], e["multi"]["mse_p99"]),
                               (single["mse_rep"], e["single"]["mse_rep"]), (single["mse_p99"], e["single"]["mse_p99"])):
                 assert abs(got - want) <= 1e-6 * abs(want), (cname, key, got, want)
+            # numpy_order: the stored answers (numpy's own float32 / float64 sums) to the last bit, both forms
+            mn = em.compute_errors(a32, b32, grouping, gs, form="multi", numpy_order=True)
+            sn = em.compute_errors(a32, b32, grouping, gs, form="single", numpy_order=True)
+            for got, want in ((mn["mse_tensor"], e["mse_tensor"]), (sn["mse_tensor"], e["mse_tensor"]),
+                              (mn["mse_rep"], e["multi"]["mse_rep"]), (mn["mse_p99"], e["multi"]["mse_p99"]),
+                              (sn["mse_rep"], e["single"]["mse_rep"]), (sn["mse_p99"], e["single"]["mse_p99"])):
+                assert got == want, (cname, key, "numpy_order", got, want)
             an = em.QuantizationErrorAnalyzer(w, deq, analysis_range=(1000, 200000))
             assert _digest(an.abs_elementwise_error.cpu().numpy()) == e["abs_sha256"]
             p99 = an.get_p99_error().cpu().numpy()
@@ -313,3 +320,25 @@ def test_percentile_unaligned_views_and_nan(em):
     b = em.percentile_batch(torch.from_numpy(x[:100000].reshape(4, 25000)).cuda(), 99).cpu().numpy()
     want = np.percentile(x[:100000].reshape(4, 25000), 99, axis=1).astype(np.float32)
     assert np.isnan(b[0]) and np.array_equal(b[1:], want[1:])
+
+
+def test_compute_errors_numpy_order_has_numpys_bits(em, oracle):
+    """compute_errors(numpy_order=True) against the scripts' numpy arithmetic (oracle.compute_errors_multi /
+    _single restate quant_error_multi_weight.py:61-87 and quant_error_single_weight.py:50-79) on arbitrary (a, b)
+    pairs: mse_tensor, mse_rep and mse_p99 equal bit for bit -- shapes whose slices are shorter than a leaf, longer
+    than numpy's 8192-element chunks (columns of 9000 rows, blocks of 64 x 300), odd row and column counts."""
+    rng = np.random.default_rng(31)
+    for K, C, gs in ((300, 64, 32), (9000, 24, 8), (77, 1000, 40), (5, 8, None), (1030, 96, None), (64, 8200, 8200)):
+        a = (rng.standard_normal((K, C)) * 0.02).astype(np.float16).astype(np.float32)
+        b = (a + rng.standard_normal((K, C)).astype(np.float32) * 1e-4).astype(np.float16).astype(np.float32)
+        ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        for grouping in (("per-channel", "per-group") if gs else ("per-channel",)):
+            wm = oracle.compute_errors_multi(a, b, grouping, gs)
+            ws = oracle.compute_errors_single(a, b, grouping, gs)
+            gm = em.compute_errors(ta, tb, grouping, gs, form="multi", numpy_order=True)
+            gsn = em.compute_errors(ta, tb, grouping, gs, form="single", numpy_order=True)
+            for k in ("mse_tensor", "mse_rep", "mse_p99"):
+                assert gm[k] == wm[k], (K, C, gs, grouping, "multi", k, gm[k], wm[k])
+                assert gsn[k] == ws[k], (K, C, gs, grouping, "single", k, gsn[k], ws[k])
+    one = em.compute_errors(ta.reshape(-1), tb.reshape(-1), "per-tensor", None, numpy_order=True)
+    assert one == {"mse_tensor": float(np.mean((a.reshape(-1) - b.reshape(-1)) ** 2))}

@@ -150,6 +150,13 @@ def test_compare_onnx_on_the_reference_quantized_exports(io, oracle):
             assert (r["datatype"], r["granularity"], r["bits"]) == (dtype, grouping, bits)
             for k in ("mse_tensor", "mse_rep", "mse_p99"):
                 assert abs(r[k] - want[k]) <= 1e-6 * abs(want[k]), (name, r["initializer"], k)
+        # numpy_order: the rows the script itself would write, to the last bit
+        for r in report.compare_onnx(base, qpath, form="multi", numpy_order=True):
+            a = params[f"block_f16/{r['initializer']}"].view(np.float16).astype(np.float32)
+            b = params[f"{name}/{r['initializer']}"].view(np.float16).astype(np.float32)
+            want = oracle.compute_errors_multi(a, b, grouping, gs)
+            for k in ("mse_tensor", "mse_rep", "mse_p99"):
+                assert r[k] == want[k], (name, r["initializer"], k, "numpy_order")
         # (2) the same model through this package's quant_model
         model = nn.ModuleDict({k: nn.Linear(*reversed(params[f"block_f16/{k}.weight"].shape), bias=False)
                                for k in ("q_proj", "up", "down")}).half().cuda()
