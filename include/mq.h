@@ -213,6 +213,10 @@ int mq_list_mean_numpy(const void* const* lists, int32_t count, int64_t n, doubl
  */
 int mq_slice_mean_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
                             float* const* out, void* hip_stream);
+/* The same slices' float32 SUMS in numpy's order, no division: np.sum(abs_err) of onnx_error_cli.py:116-117,
+ * :125-127. */
+int mq_slice_sum_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
+                           float* const* out, void* hip_stream);
 
 /*
  * The report rows of one pass (the CSV rows of quant_error_multi_weight.py:142-151 before formatting): for tensor i

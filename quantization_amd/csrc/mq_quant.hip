@@ -2126,6 +2126,7 @@ struct ListBatch {
   const float* x[MQ_LIST_BATCH];
   void* out[MQ_LIST_BATCH];
   int64_t n;       // every list of a launch has this length
+  int32_t sum_only;  // 1: the sum itself (np.sum), no division
   int64_t run, S;  // element t of a list is x[(t / run) * S + t % run]: runs of `run` contiguous values, S elements
                    // apart (a contiguous list: run = n; a column of a row-major matrix: run = 1, S = columns; a block
                    // of gs columns in numpy's C order: run = gs, S = columns)
@@ -2184,8 +2185,8 @@ __global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if constexpr (sizeof(Acc) == 8) *static_cast<double*>(b.out[blockIdx.x]) = total / (double)b.n;
-    else *static_cast<float*>(b.out[blockIdx.x]) = (float)((double)total / (double)b.n);
+    if constexpr (sizeof(Acc) == 8) *static_cast<double*>(b.out[blockIdx.x]) = b.sum_only ? total : total / (double)b.n;
+    else *static_cast<float*>(b.out[blockIdx.x]) = b.sum_only ? total : (float)((double)total / (double)b.n);
   }
 }
 
@@ -3042,11 +3043,12 @@ extern "C" int mq_tensor_mse_numpy(const void* w, int32_t w_dtype, int64_t rows,
 }
 
 static int list_mean_launch(const void* const* lists, int32_t count, int64_t n, int64_t run, int64_t stride,
-                            void* const* out, bool f64, hipStream_t st) {
+                            void* const* out, bool f64, hipStream_t st, bool sum_only = false) {
   if (count < 0 || n < 1 || run < 1 || (count > 0 && (!lists || !out))) return MQ_ERR_ARG;
   if (run > n || n % run || (run != n && stride < run)) return MQ_ERR_ARG;
   ListBatch b = {};
   b.n = n;
+  b.sum_only = sum_only ? 1 : 0;
   b.run = run;
   b.S = stride;
   if (!list_prog(n < 8192 ? 0 : 8192, &b.full) || !list_prog(n % 8192, &b.tail)) return MQ_ERR_UNSUPPORTED;
@@ -3068,6 +3070,11 @@ extern "C" int mq_list_mean_numpy(const void* const* lists, int32_t count, int64
                                   void* hip_stream) {
   return list_mean_launch(lists, count, n, n, n, reinterpret_cast<void* const*>(out), true,
                           static_cast<hipStream_t>(hip_stream));
+}
+extern "C" int mq_slice_sum_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
+                                      float* const* out, void* hip_stream) {
+  return list_mean_launch(firsts, count, n, run, stride, reinterpret_cast<void* const*>(out), false,
+                          static_cast<hipStream_t>(hip_stream), true);
 }
 extern "C" int mq_slice_mean_numpy_f32(const void* const* firsts, int32_t count, int64_t n, int64_t run, int64_t stride,
                                        float* const* out, void* hip_stream) {

@@ -274,11 +274,12 @@ def compute_mse(a, b) -> float:
     return float(st["totals"][0].item() / n) if n else float("nan")
 
 
-def slice_means_numpy(sq: torch.Tensor, offsets: Sequence[int], n: int, run: int, stride: int) -> torch.Tensor:
+def slice_means_numpy(sq: torch.Tensor, offsets: Sequence[int], n: int, run: int, stride: int,
+                      sums: bool = False) -> torch.Tensor:
     """np.mean of slices of the contiguous float32 tensor `sq`, bit for bit (mq_slice_mean_numpy_f32): slice i starts
     at element offsets[i] and holds n values in runs of `run` contiguous ones, `stride` elements apart -- a column of
     a [K, C] matrix: n = K, run = 1, stride = C; a block of gs columns: n = K * gs, run = gs; a row: run = n = C.
-    -> float32 [len(offsets)]."""
+    sums: np.sum instead (mq_slice_sum_numpy_f32).  -> float32 [len(offsets)]."""
     from .fused import bind_batch
     L = bind_batch()
     if sq.dtype != torch.float32 or not sq.is_contiguous():
@@ -287,8 +288,8 @@ def slice_means_numpy(sq: torch.Tensor, offsets: Sequence[int], n: int, run: int
     base, ob = sq.data_ptr(), out.data_ptr()
     firsts = (ctypes.c_void_p * len(offsets))(*[base + 4 * int(o) for o in offsets])
     outs = (ctypes.c_void_p * len(offsets))(*[ob + 4 * i for i in range(len(offsets))])
-    _lib.check(L.mq_slice_mean_numpy_f32(firsts, len(offsets), n, run, stride, outs,
-                                         torch.cuda.current_stream(sq.device).cuda_stream))
+    fn = L.mq_slice_sum_numpy_f32 if sums else L.mq_slice_mean_numpy_f32
+    _lib.check(fn(firsts, len(offsets), n, run, stride, outs, torch.cuda.current_stream(sq.device).cuda_stream))
     return out
 
 
@@ -365,7 +366,12 @@ class QuantizationErrorAnalyzer:
     the matplotlib plots stay on the CPU side): float32 element-wise error, its absolute value, P99 and
     sum, and MSE / absolute-error sum of an index range."""
 
-    def __init__(self, w_fp16: torch.Tensor, w_quant: torch.Tensor, analysis_range: Optional[tuple] = None):
+    def __init__(self, w_fp16: torch.Tensor, w_quant: torch.Tensor, analysis_range: Optional[tuple] = None,
+                 numpy_order: bool = False):
+        """numpy_order: the sums and the sliced mean in numpy's float32 summation order -- get_error_sum,
+        get_sliced_mse and get_sliced_abs_error_sum then return the script's float32 values bit for bit (default:
+        float64 sums, equal to 1e-6)."""
+        self.numpy_order = bool(numpy_order)
         self.w_fp16 = require_device(w_fp16).float().reshape(-1)   # _load_weight: .astype(np.float32) (:110)
         self.w_quant = require_device(w_quant).float().reshape(-1)
         st = error_stats(self.w_fp16, self.w_quant, abs_err=torch.float32)
@@ -387,14 +393,32 @@ class QuantizationErrorAnalyzer:
         """np.percentile(abs_err, 99) (:113-114): float32, bit-exact."""
         return percentile(self.abs_elementwise_error, 99)
 
+    def _range(self):
+        start, end = self.analysis_range
+        return start, min(end, self.w_fp16.numel())
+
     def get_error_sum(self) -> float:
-        """np.sum(abs_err) (:116-117); accumulated in float64 here."""
+        """np.sum(abs_err) (:116-117); accumulated in float64 here, or -- numpy_order -- in numpy's float32 order."""
+        if self.numpy_order:
+            x = self.abs_elementwise_error.contiguous()
+            return float(slice_means_numpy(x, [0], x.numel(), x.numel(), x.numel(), sums=True)[0].item())
         return float(self._totals[1].item())
 
     def get_sliced_mse(self) -> float:
+        """np.mean(sliced_error ** 2) (:119-123)."""
+        if self.numpy_order and self._sliced:
+            start, end = self._range()
+            d = (self.w_fp16[start:end] - self.w_quant[start:end])
+            sq = (d * d).contiguous()
+            return float(slice_means_numpy(sq, [0], sq.numel(), sq.numel(), sq.numel())[0].item())
         return float(self._sliced["totals"][0].item() / self._sliced_n) if self._sliced else 0.0
 
     def get_sliced_abs_error_sum(self) -> float:
+        """np.sum(np.abs(sliced_error)) (:125-127)."""
+        if self.numpy_order and self._sliced:
+            start, end = self._range()
+            x = self.abs_elementwise_error[start:end].contiguous()
+            return float(slice_means_numpy(x, [0], x.numel(), x.numel(), x.numel(), sums=True)[0].item())
         return float(self._sliced["totals"][1].item()) if self._sliced else 0.0
 
     def abs_error_histogram(self, bins: int = 200, range=None):

@@ -241,6 +241,8 @@ def bind_batch():
         L_.mq_list_mean_numpy.argtypes = [ctypes.POINTER(vp), i32, i64, ctypes.POINTER(vp), vp]
         L_.mq_slice_mean_numpy_f32.restype = ctypes.c_int
         L_.mq_slice_mean_numpy_f32.argtypes = [ctypes.POINTER(vp), i32, i64, i64, i64, ctypes.POINTER(vp), vp]
+        L_.mq_slice_sum_numpy_f32.restype = ctypes.c_int
+        L_.mq_slice_sum_numpy_f32.argtypes = L_.mq_slice_mean_numpy_f32.argtypes
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

@@ -114,6 +114,10 @@ def test_known_answers(em, oracle):
             want_ssum = float(np.uint32(e["sliced_abs_sum_f32_bits"]).view(np.float32))
             assert abs(an.get_sliced_mse() - want_smse) <= 1e-6 * want_smse
             assert abs(an.get_sliced_abs_error_sum() - want_ssum) <= 1e-6 * want_ssum
+            # numpy_order: the script's float32 sums and sliced mean, to the last bit
+            ann = em.QuantizationErrorAnalyzer(w, deq, analysis_range=(1000, 200000), numpy_order=True)
+            assert ann.get_error_sum() == want_sum and ann.get_sliced_mse() == want_smse
+            assert ann.get_sliced_abs_error_sum() == want_ssum
             abs16, idx, values = em.bucketize(w, deq)
             assert _digest(abs16.view(torch.int16).cpu().numpy().view(np.uint16)) == e["abs_f16_sha256"]
             assert _digest(idx.cpu().numpy().astype(np.int64)) == e["bucket_idx_sha256"]
