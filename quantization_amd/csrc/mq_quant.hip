@@ -2178,7 +2178,14 @@ __global__ __launch_bounds__(128) void k_list_mean_numpy(const ListBatch b) {
     const uint16_t* off = is_tail ? off_tail : off_full;
     if ((int)threadIdx.x < pr.nleaves) leaf[threadIdx.x] = numpy_leaf<Acc>(b, x, c0 + off[threadIdx.x], pr.len[threadIdx.x]);
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (!is_tail) {
+      // a whole chunk: 64 leaves of 128 values, a perfect tree -- neighbours first, the left operand on the left
+      for (int w2 = 1; w2 < 64; w2 <<= 1) {
+        if (threadIdx.x < 64 && (threadIdx.x & (2 * w2 - 1)) == 0) leaf[threadIdx.x] = leaf[threadIdx.x] + leaf[threadIdx.x + w2];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) total = c0 == 0 ? leaf[0] : total + leaf[0];
+    } else if (threadIdx.x == 0) {
       const Acc c = numpy_run_prog<Acc>(pr.ops, pr.nops, &leaf[0]);
       total = c0 == 0 ? c : total + c;
     }
