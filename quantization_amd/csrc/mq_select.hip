@@ -681,17 +681,18 @@ __global__ __launch_bounds__(1024) void k_sel_cand(const SelBatch b, const SelRa
       if ((key & himask) == p0) atomicAdd(&hist[0][d], 1u);
       if (!same && (key & himask) == p1) atomicAdd(&hist[1][d], 1u);
     };
-    // 16-byte loads, four in flight per thread (one workgroup walks the list: the loop is bound by load latency)
+    // 16-byte loads, eight in flight per thread (one workgroup walks the list: the loop is bound by load latency)
     const uint64_t nvec = n / 4;
-    for (uint64_t v0 = threadIdx.x; v0 < nvec; v0 += 4 * blockDim.x) {
-      u32x4 raw[4];
+    constexpr int U = 8;  // loads in flight per thread
+    for (uint64_t v0 = threadIdx.x; v0 < nvec; v0 += U * blockDim.x) {
+      u32x4 raw[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const uint64_t v = v0 + (uint64_t)u * blockDim.x;
         raw[u] = v < nvec ? reinterpret_cast<const u32x4*>(x)[v] : u32x4{0, 0, 0, 0};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (v0 + (uint64_t)u * blockDim.x >= nvec) break;
 #pragma unroll
         for (int j = 0; j < 4; ++j) put(raw[u][j]);
