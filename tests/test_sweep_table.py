@@ -107,3 +107,45 @@ def test_what_the_sweep_form_refuses(L):
     assert _prepare(L, ok, 128, table_bytes=64)[0] == _lib.ERR_WORKSPACE
     assert _prepare(L, ok, 128, seg_sse=0x7000000004 + 0, seg_flag=0)[0] == _lib.ERR_ALIGN   # float64 sums, 4-byte aligned
     assert _prepare(L, [(0, 4096)], 128)[0] == A
+
+
+def test_numpy_order_entry_points_refuse_bad_arguments_before_any_launch(L):
+    """The argument checks of mq_list_mean_numpy, mq_slice_mean_numpy_f32 / mq_slice_sum_numpy_f32 and
+    mq_tensor_mse_numpy come before the first HIP call: their status codes can be checked without a device."""
+    i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    L.mq_list_mean_numpy.restype = ctypes.c_int
+    L.mq_list_mean_numpy.argtypes = [ctypes.POINTER(vp), i32, i64, ctypes.POINTER(vp), vp]
+    for fn in (L.mq_slice_mean_numpy_f32, L.mq_slice_sum_numpy_f32):
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(vp), i32, i64, i64, i64, ctypes.POINTER(vp), vp]
+    L.mq_tensor_mse_numpy_workspace_bytes.restype = sz
+    L.mq_tensor_mse_numpy_workspace_bytes.argtypes = [i64, i64]
+    L.mq_tensor_mse_numpy.restype = ctypes.c_int
+    L.mq_tensor_mse_numpy.argtypes = [vp, i32, i64, i64, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp, vp, sz, vp]
+    A, U, G = _lib.ERR_ARG, _lib.ERR_UNSUPPORTED, _lib.ERR_GROUP
+    xs = (vp * 2)(0x10000000, 0x10001000)
+    out = (vp * 2)(0x20000000, 0x20000008)
+    assert L.mq_list_mean_numpy(xs, 2, 0, out, None) == A                    # empty lists have no mean
+    assert L.mq_list_mean_numpy(None, 2, 100, out, None) == A
+    assert L.mq_list_mean_numpy(xs, 0, 100, out, None) == _lib.OK            # nothing to do
+    bad = (vp * 2)(0x10000002, 0x10001000)
+    assert L.mq_list_mean_numpy(bad, 2, 100, out, None) == _lib.ERR_ALIGN
+    assert L.mq_slice_mean_numpy_f32(xs, 2, 100, 0, 8, out, None) == A       # runs of no values
+    assert L.mq_slice_mean_numpy_f32(xs, 2, 100, 30, 64, out, None) == A     # the runs do not tile the slice
+    assert L.mq_slice_mean_numpy_f32(xs, 2, 100, 20, 8, out, None) == A      # runs that overlap
+    assert L.mq_slice_sum_numpy_f32(xs, 2, -5, 1, 8, out, None) == A
+    cfg = _lib.QuantCfg(format=_lib.INT_SYM, bits=8, group_size=128)
+    w, sc, mo, ws = 0x30000000, 0x40000000, 0x50000000, 0x60000000
+    nb = L.mq_tensor_mse_numpy_workspace_bytes(64, 1024)
+    assert nb == 256 + 8 * 4                                                  # 65536 elements: eight chunks of 8192
+    call = lambda **k: L.mq_tensor_mse_numpy(k.get("w", w), k.get("dt", _lib.BF16), k.get("rows", 64), k.get("cols", 1024),
+                                             ctypes.byref(k.get("cfg", cfg)), k.get("sc", sc), k.get("zp", None), mo,
+                                             k.get("ws", ws), k.get("nb", nb), None)
+    assert call(dt=_lib.F32) == U and call(dt=7) == A
+    assert call(sc=None) == A and call(rows=0) == A
+    assert call(cfg=_lib.QuantCfg(format=_lib.INT_ASYM, bits=8, group_size=128)) == A     # asymmetric without zero-points
+    assert call(cfg=_lib.QuantCfg(format=_lib.INT_SYM, bits=8, group_size=100)) == G      # 1024 % 100
+    assert call(cfg=_lib.QuantCfg(format=_lib.INT_SYM, bits=8, group_size=4)) == U        # a vector would straddle groups
+    assert call(w=w + 2) == U                                                              # weights off the 16-byte grid
+    assert call(nb=nb - 1) == _lib.ERR_WORKSPACE and call(ws=None) == _lib.ERR_WORKSPACE
+    assert call(cfg=_lib.QuantCfg(format=_lib.INT_SYM, bits=9, group_size=128)) == U
