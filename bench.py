@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--workload", default="llama8b",
                     choices=["llama8b", "llama70b", "tinyllama", "c2", "c3", "llama70b_shard"])
     ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
+    ap.add_argument("--numpy-order", action="store_true",
+                    help="model sweeps: every mean in numpy's summation order (mse_tensor / mse_rep / mse_p99 in the "
+                         "reference's bits); a correctness mode, an order of magnitude slower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the c2 and llama70b_shard results")
     ap.add_argument("--watchdog", type=int, default=0, metavar="SECONDS",
@@ -103,7 +106,7 @@ def algorithmic_bytes_per_elem(in_bytes, lut, asym, gs, outputs):
 class ModelSweep:
     """The sharded model sweep (configs [0], [3], [4]): this rank's layers of the model, every pass of the sweep."""
 
-    def __init__(self, name, device, rank, world, dist_name):
+    def __init__(self, name, device, rank, world, dist_name, numpy_order=False):
         import torch
         from quantization_amd import shapes
         from quantization_amd.distributed import lpt_partition
@@ -134,6 +137,7 @@ class ModelSweep:
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
         self.plan = None
+        self.numpy_order = bool(numpy_order)
         self.overlap = True   # selections of pass k on a second stream under the launches of pass k + 1
         # the per-channel lists of the first format feed the model-wide percentile
         self.joint_pass = next(k for k, (_, _, gs) in enumerate(self.passes) if gs is None)
@@ -161,7 +165,7 @@ class ModelSweep:
             # every pass of the sweep over this rank's resident layers (launch descriptors and buffers prepared once);
             # the per-channel lists of the first format feed the model-wide percentile
             if self.plan is None:
-                self.plan = SweepPlan(self.weights, self.passes)
+                self.plan = SweepPlan(self.weights, self.passes, numpy_order=self.numpy_order)
             self.plan.launch(overlap=self.overlap)
             vecs = self.plan.lists(self.joint_pass)
         # RCCL: the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists -- enqueued
@@ -447,7 +451,7 @@ def main():
 
     sharded = args.workload in MODEL_OF
     if sharded:
-        wl = ModelSweep(args.workload, device, rank, world, args.dist)
+        wl = ModelSweep(args.workload, device, rank, world, args.dist, numpy_order=args.numpy_order)
         total_weight_bytes, local_algo, reserve = wl.total_weight_bytes, wl.local_algo_bytes, wl.launches_hint
     else:
         if world > 1:
@@ -490,10 +494,11 @@ def main():
             "config": {"workload": f"{args.workload}: {wl.desc}",
                        "passes_per_step": len(wl.passes) if sharded else wl.launches,
                        "weight_bytes_per_step_whole_job": int(total_weight_bytes),
-                       "gpu_ms_per_step_events_rank0": round(gpu_ms / args.steps, 4)},
+                       "gpu_ms_per_step_events_rank0": round(gpu_ms / args.steps, 4),
+                       **({"numpy_order": True} if args.numpy_order else {})},
             "roofline": roofline(local_algo, args.steps, kern_ms, kern_launches, wl.kernel_desc + " (rank 0)",
                                  # (the PMC passes measured the one-GPU launches: a shard's launches are smaller)
-                                 traffic_for(args.workload) if world == 1 else None),
+                                 traffic_for(args.workload) if world == 1 and not args.numpy_order else None),
         }
         if isolated:
             out["roofline"]["launch_alone"] = isolated
