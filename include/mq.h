@@ -119,6 +119,18 @@ int mq_profile_end(double* total_ms, int64_t* launches);
  */
 int mq_selfcheck_div16(uint64_t* counts, void* hip_stream);
 
+/*
+ * Device self-check (no counterpart in the reference): does the hardware's packed float32 -> fp8 e4m3 conversion
+ * (v_cvt_pk_fp8_f32, decoded again by v_cvt_f32_fp8) round like the reference's FP8_E4M3 value table -- nearest table
+ * value, ties toward -inf, largest value 480, no subnormals (quant_weight.py:114-138, :577-601)?  Every finite
+ * float16 x with |x| <= 480 is tried.  counts (DEVICE, 5 x uint64, 8-byte aligned) receives: values checked; values
+ * where hardware and table differ; of those, exact ties between two table values; of those, |x| above 448 (the
+ * hardware format's largest finite value); of those, |x| below 2^-6, the hardware format's smallest normal value
+ * (it continues with subnormals of step 2^-9; the table keeps three mantissa bits down to 1.125 * 2^-7).  A non-zero second count is the reason the kernels round e4m3 in integer
+ * bit arithmetic (lut_round_*), as they do e3m4, which has no hardware format.
+ */
+int mq_selfcheck_fp8_cvt(uint64_t* counts, void* hip_stream);
+
 /* Bytes of device workspace mq_quantize needs for this shape (reduction slots + per-block partials). */
 size_t mq_quantize_workspace_bytes(int64_t rows, int64_t cols, const mq_quant_cfg* cfg);
 

@@ -2621,6 +2621,60 @@ extern "C" int mq_selfcheck_div16(uint64_t* counts_device, void* hip_stream) {
   return MQ_OK;
 }
 
+// Does the hardware's packed float32 -> fp8 (e4m3) conversion round like the reference's FP8_E4M3 table (nearest
+// table value, ties toward -inf, largest value 480, no inf / NaN: quant_weight.py:114-138, :577-601)?  Every finite
+// float16 x with |x| <= 480 (the scaled weights' range) goes through v_cvt_pk_fp8_f32 and back (v_cvt_f32_fp8) and
+// through lut_round_bits.  counts[0]: values checked; [1]: values where the two differ; [2]: of those, exact ties
+// between two table values; [3]: of those, |x| above 448 (the hardware format's largest finite value); [4]: of
+// those, |x| below 2^-6, the hardware format's smallest normal value (it continues with subnormals of step 2^-9;
+// the table keeps three mantissa bits down to 1.125 * 2^-7 and has nothing between that and 0).
+__global__ __launch_bounds__(256) void k_selfcheck_fp8_cvt(LutConst lut, unsigned long long* counts) {
+  const uint32_t xb = blockIdx.x * 256u + threadIdx.x;  // all 65536 float16 bit patterns
+  const uint32_t mag = xb & 0x7fffu;
+  unsigned long long n = 0, bad = 0, tie = 0, top = 0, low = 0;
+  if (mag <= 0x5f80u) {  // |x| <= 480
+    const float xf = (float)h_from_bits(xb);
+    const int packed = __builtin_amdgcn_cvt_pk_fp8_f32(xf, xf, 0, false);
+    const float hw = __builtin_amdgcn_cvt_f32_fp8(packed, 0);
+    const float ref = (float)h_from_bits(lut_round_bits(xb, 0x8000u, 0x7c00u, lut));
+    n = 1;
+    if (!(hw == ref)) {  // (a NaN from the hardware counts as different; +0 == -0)
+      bad = 1;
+      // a tie: |x| has exactly the bit below the kept mantissa bits set
+      const uint32_t below = mag & ((1u << lut.shift) - 1u);
+      tie = below == (1u << (lut.shift - 1)) ? 1 : 0;
+      top = mag > 0x5f00u ? 1 : 0;          // > 448
+      low = mag < 0x2400u ? 1 : 0;           // < 2^-6
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n += __shfl_xor(n, off); bad += __shfl_xor(bad, off); tie += __shfl_xor(tie, off); top += __shfl_xor(top, off);
+    low += __shfl_xor(low, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], n); atomicAdd(&counts[1], bad); atomicAdd(&counts[2], tie); atomicAdd(&counts[3], top);
+    atomicAdd(&counts[4], low);
+  }
+}
+extern "C" int mq_selfcheck_fp8_cvt(uint64_t* counts_device, void* hip_stream) {
+  if (!counts_device) return MQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(counts_device) % 8) return MQ_ERR_ALIGN;
+  mq_quant_cfg cfg = {};
+  cfg.format = MQ_LUT_FP;
+  cfg.bits = 8;
+  cfg.exp_bits = 4; cfg.man_bits = 3; cfg.exp_bias = 7;
+  LutConst lut;
+  float lutmax;
+  if (!lut_consts(&cfg, false, &lut, &lutmax)) return MQ_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  MQ_HIP(hipMemsetAsync(counts_device, 0, 5 * sizeof(uint64_t), st));
+  hipLaunchKernelGGL(k_selfcheck_fp8_cvt, dim3(256), dim3(256), 0, st, lut,
+                     reinterpret_cast<unsigned long long*>(counts_device));
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
 static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; }
 
 // One launch (plus one finalize launch when totals are requested) for up to MQ_MAX_BATCH tensors.

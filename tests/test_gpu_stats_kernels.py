@@ -291,3 +291,24 @@ def test_numpy_order_tensor_mse_is_bit_exact(oracle, fmt, dt):
         # and against the float64 sum of the bandwidth kernels: the 1e-6 bar
         ref = float(res.totals[0].item()) / (rows * cols)
         assert np.isnan(ref) == bool(np.isnan(got)) and (np.isnan(ref) or abs(float(got) - ref) <= 1e-6 * ref)
+
+
+def test_hardware_fp8_conversion_does_not_round_like_the_reference_table():
+    """mq_selfcheck_fp8_cvt: the CDNA4 packed float32 -> fp8 e4m3 conversion against the reference's FP8_E4M3 table
+    rounding (quant_weight.py:114-138, :577-601) on every float16 x with |x| <= 480.  They differ -- on ties (round
+    to nearest even against ties toward -inf), above 448 (the hardware format ends there, the table goes to 480) and
+    below 2^-6 (hardware subnormals against the table's e = 0 binade) -- which is why e4m3 is rounded in integer bit
+    arithmetic.
+    The counts are recorded here so that a toolchain or hardware change shows up."""
+    import ctypes
+    from quantization_amd import _lib
+    L = _lib.lib()
+    L.mq_selfcheck_fp8_cvt.restype = ctypes.c_int
+    L.mq_selfcheck_fp8_cvt.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    counts = torch.full((5,), -1, dtype=torch.int64, device="cuda")
+    _lib.check(L.mq_selfcheck_fp8_cvt(counts.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    checked, differ, ties, top, low = counts.cpu().tolist()
+    print("fp8 e4m3 hardware conversion vs table:", checked, differ, ties, top, low)
+    assert checked == 2 * (0x5f80 + 1)          # every float16 pattern of either sign up to 480
+    assert differ > 0 and ties > 0 and top > 0  # the conversion is not the table's rounding
+    assert ties + top + low >= differ           # and every difference is one of the three known kinds
