@@ -18,10 +18,12 @@ weights of Llama-3-70B (139 GB) with int8 sym / asym, fp8_e4m3, fp8_e3m4 x {per-
 this process touches a GPU); under torch.distributed.run it must equal WORLD_SIZE.  MQ_BENCH_BACKEND=gloo
 rehearses the multi-rank path on a box with fewer GPUs than ranks.
 
-At N = 1 the same JSON line carries two more driver-timed results under "extra": "c2" (configs[1]: 16 x
-4096 x 4096 fp16, asymmetric int8 g = 32 / 64 / 128 with dequantized weights, codes, scales, zero-points, the
-float32 |error| dump and its exact P99 selected inside the pass) and "llama70b_shard" (one GPU's eighth of the
-Llama-3-70B sweep), each with its own roofline object; and the CPU baseline.
+At N = 1 the same JSON line carries the 1-GPU leg of every other BASELINE configuration under "extra", each timed the
+same way with its own roofline object: "c1_tinyllama" (configs[0]), "c2" (configs[1]: 16 x 4096 x 4096 fp16,
+asymmetric int8 g = 32 / 64 / 128 with dequantized weights, codes, scales, zero-points, the float32 |error| dump and
+its exact P99 selected inside the pass), "c3" (configs[2]: three dequantized formats + the compare.py masks),
+"llama70b_shard" (one GPU's eighth of configs[4]) and "c5_llama70b" (configs[4] whole on one GPU: 139 GB resident);
+and the CPU baseline.  Every step ends with the statistics copied to host memory (inside the timed region).
 
 One JSON line is printed by rank 0.
 """
@@ -65,8 +67,9 @@ def parse_args():
                          "reference's bits); a correctness mode, an order of magnitude slower")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the c2 and llama70b_shard results")
-    ap.add_argument("--watchdog", type=int, default=0, metavar="SECONDS",
-                    help="every rank: after SECONDS print all Python stacks to stderr and exit (a hang names itself)")
+    ap.add_argument("--watchdog", type=int, default=None, metavar="SECONDS",
+                    help="every rank: after SECONDS print all Python stacks to stderr and exit non-zero (a hang names "
+                         "itself); default 300 with more than one rank, off with one; 0 = off")
     return ap.parse_args()
 
 
@@ -137,6 +140,7 @@ class ModelSweep:
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
         self.plan = None
+        self.host_table = self.host_p99 = None
         self.numpy_order = bool(numpy_order)
         self.overlap = True   # selections of pass k on a second stream under the launches of pass k + 1
         # the per-channel lists of the first format feed the model-wide percentile
@@ -175,7 +179,14 @@ class ModelSweep:
             local = self.plan.finish().reshape(-1, len(RECORD_FIELDS))
         # ... and one all-reduce of the zero-filled record table of the whole sweep
         table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
-        return table, model_p99
+        # the statistics leave the device inside the step: the record table (tens of KiB) and the model-wide P99 go
+        # to pinned host memory on the step's stream; the timed region ends with a synchronize, so they have arrived
+        if self.host_table is None:
+            self.host_table = torch.empty(table.shape, dtype=table.dtype, pin_memory=True)
+            self.host_p99 = torch.empty((), dtype=model_p99.dtype, pin_memory=True)
+        self.host_table.copy_(table, non_blocking=True)
+        self.host_p99.copy_(model_p99, non_blocking=True)
+        return self.host_table, self.host_p99
 
 
 class Workload:
@@ -203,6 +214,7 @@ class Workload:
         self.compare = None
         self.sweep = None     # llama70b_shard: (weights, passes) of a report.SweepPlan
         self.plan = None
+        self.host_rec = None
         self.overlap = True
         self.batches = []  # (stacked weights [B, rows, cols], fmt, datatype, gs, outputs dict)
         self.results = {}
@@ -282,7 +294,7 @@ class Workload:
             if self.plan is None:
                 from quantization_amd.report import SweepPlan
                 self.plan = SweepPlan(*self.sweep)
-            return self.plan.run(overlap=self.overlap)
+            return self.to_host(self.plan.run(overlap=self.overlap))
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):
             res = self.results.get(k)
@@ -302,7 +314,7 @@ class Workload:
             for w, idxs, flags in self.compare:
                 compare_formats(w, [results[i].deq for i in idxs], 0.02, out=flags)
             rec[:, 0:2] = self.totals
-            return rec
+            return self.to_host(rec)
         rec[:, 0:2] = self.totals
         # mean of a tensor's per-vector MSE list = its tensor MSE (all vectors have one length); the P99 is selected
         # on the float32 list entries and interpolated in float64, as np.percentile of the scripts' float64 list
@@ -310,7 +322,15 @@ class Workload:
         rec[:, 3] = percentile_rows([res.seg_mse for res in results], 99, wide=True)
         if results[0].abs_p99 is not None:
             rec[:, 4] = torch.cat([res.abs_p99 for res in results])     # exact P99 of |err| (float32)
-        return rec
+        return self.to_host(rec)
+
+    def to_host(self, rec):
+        """The step's statistics leave the device inside the step (pinned memory, the step's stream)."""
+        import torch
+        if self.host_rec is None:
+            self.host_rec = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
+        self.host_rec.copy_(rec, non_blocking=True)
+        return self.host_rec
 
 
 def cpu_baseline():
@@ -421,9 +441,12 @@ def main():
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(world_env or "1")
-    if args.watchdog > 0:
+    # first contact with RCCL must fail loudly, not hang: with more than one rank every rank arms a watchdog that
+    # prints all Python stacks and leaves with a non-zero status (no re-exec; the launcher then ends the others)
+    watchdog = args.watchdog if args.watchdog is not None else (300 if world > 1 else 0)
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(args.watchdog, exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
@@ -459,6 +482,11 @@ def main():
             sys.exit(2)
         wl = Workload(args.workload, device, rank, args.dist)
         total_weight_bytes, local_algo, reserve = wl.weight_bytes, wl.algo_bytes, wl.launches
+    if sharded and world > 1:
+        # every rank names its shard and what it sees before the first collective of the data path
+        print(f"bench.py rank {rank}/{world}: device {device} ({torch.cuda.get_device_name(device)}), backend {backend}, "
+              f"dist world {dist.get_world_size()}, {len(wl.mine)} layers, {wl.local_weight_bytes} weight bytes per step, "
+              f"watchdog {watchdog} s", file=sys.stderr, flush=True)
     wall, gpu_ms, kern_ms, kern_launches = timed_run(wl.step, args.steps, args.warmup, device, dist, world, reserve)
     isolated = None
     if sharded or getattr(wl, "sweep", None) is not None:
@@ -510,21 +538,31 @@ def main():
                 if world > 1 else "none",
                 "weight_bytes_per_step_per_rank": [s[0] for s in shares], "layers_per_rank": [s[1] for s in shares]})
 
-    # N = 1: the other two driver-timed results and the CPU baseline
+    # N = 1: the 1-GPU leg of every other configuration, driver-timed in the same run, and the CPU baseline
     if world == 1 and rank == 0 and sharded and args.workload == "llama8b" and not args.no_extra:
         del wl
         torch.cuda.empty_cache()
         out["extra"] = {}
-        for name, steps, warm in (("c2", 20, 3), ("llama70b_shard", 3, 1)):
-            w2 = Workload(name, device, 0, args.dist)
-            wall2, gpu2, k2, n2 = timed_run(w2.step, steps, warm, device, None, 1, w2.launches)
-            out["extra"][name] = {
-                "value": round(w2.weight_bytes * steps / wall2 / 1e9, 2), "unit": "GB/s", "steps": steps, "warmup": warm,
-                "ms_per_step": round(wall2 / steps * 1e3, 4), "workload": w2.desc,
-                "weight_bytes_per_step": int(w2.weight_bytes),
-                "roofline": roofline(w2.algo_bytes, steps, k2, n2, w2.kernel_desc, traffic_for(name))}
-            if w2.sweep is not None:
-                out["extra"][name]["roofline"]["launch_alone"] = launch_alone(w2, device, None, 1, w2.launches, w2.algo_bytes)
+        extras = (("c1_tinyllama", "tinyllama", 20, 3), ("c2", "c2", 20, 3), ("c3", "c3", 10, 2),
+                  ("llama70b_shard", "llama70b_shard", 3, 1), ("c5_llama70b", "llama70b", 2, 1))
+        for key, name, steps, warm in extras:
+            if name in MODEL_OF:
+                if name == "llama70b" and torch.cuda.mem_get_info(device)[0] < 230e9:
+                    out["extra"][key] = {"skipped": "needs 139 GB of weights + 61 GB of per-vector lists resident"}
+                    continue
+                w2 = ModelSweep(name, device, 0, 1, args.dist)
+                wbytes, algo, hint, desc = w2.total_weight_bytes, w2.local_algo_bytes, w2.launches_hint, w2.desc
+            else:
+                w2 = Workload(name, device, 0, args.dist)
+                wbytes, algo, hint, desc = w2.weight_bytes, w2.algo_bytes, w2.launches, w2.desc
+            wall2, gpu2, k2, n2 = timed_run(w2.step, steps, warm, device, None, 1, hint)
+            out["extra"][key] = {
+                "value": round(wbytes * steps / wall2 / 1e9, 2), "unit": "GB/s", "steps": steps, "warmup": warm,
+                "ms_per_step": round(wall2 / steps * 1e3, 4), "workload": f"{name}: {desc}",
+                "weight_bytes_per_step": int(wbytes),
+                "roofline": roofline(algo, steps, k2, n2, w2.kernel_desc, traffic_for(name))}
+            if name in MODEL_OF or w2.sweep is not None:
+                out["extra"][key]["roofline"]["launch_alone"] = launch_alone(w2, device, None, 1, hint, algo)
             del w2
             torch.cuda.empty_cache()
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

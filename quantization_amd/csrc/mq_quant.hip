@@ -2321,6 +2321,7 @@ static bool recip_ok_cached(float c) {
 #if MQ_PART >= 1
 template <int FMT, int NV, int SEL>
 static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
+  static_assert(SEL_FEED_THREADS == 256, "the feeding kernels' candidate stages assume four waves per workgroup");
   switch (team_log2) {
     case 0: hipLaunchKernelGGL((k_quant_team<FMT, 1, NV, SEL>), grid, dim3(256), lds, st, p); break;
     case 1: hipLaunchKernelGGL((k_quant_team<FMT, 2, NV, SEL>), grid, dim3(256), lds, st, p); break;

@@ -17,6 +17,8 @@
 #define SEL_BR_MIN_N (1 << 21)
 #define SEL_FEED_HASH 2048   // LDS table of a feeding kernel: keys[2048] + counts[2048] = 16 KiB
 #define SEL_CAND_MAX (SEL_BR_BINS * 65536)  // capacity of the candidate list that overlays br_fine
+#define SEL_FEED_THREADS 256 // workgroup size of a feeding kernel (four candidate stages share the LDS table)
+static_assert((2 * SEL_FEED_HASH) / (SEL_FEED_THREADS / 64) >= 1 + 511 + 8 * 64, "candidate stage of a wave");
 
 struct SelState {
   uint64_t prefix[2];  // resolved high bits of the two keys, left-aligned in 63 bits
@@ -116,6 +118,8 @@ __device__ __forceinline__ void sel_feed_init(SelFeed& f, SelWs* ws, uint32_t* l
     f.lo = ws->br_lo;
     f.nb = ws->br_nb;
     f.shift = ws->br_shift;
+    // (a stage must hold its count word, up to 511 entries left from before and the 8 x 64 of one vector: feeding
+    //  kernels are launched with SEL_FEED_THREADS threads, which the host side checks)
     f.cand_words = (2 * SEL_FEED_HASH) / (blockDim.x >> 6);
     __syncthreads();
   }
@@ -152,16 +156,24 @@ __device__ __forceinline__ void sel_feed_add(SelFeed& f, uint32_t key, uint32_t*
 // Their exact bit patterns are kept: each wave stages them in its slice of the LDS area (word 0: count) and
 // appends full stages to the list in ws->br_fine with one global atomic; a small kernel then selects among the
 // list (k_sel_cand), so the stored array is not read again.
-__device__ __forceinline__ void sel_feed_cand_flush(SelFeed& f) {  // whole wave, converged
+// Called by whichever lanes of the wave are active (the per-element path of a kernel runs under a per-segment
+// branch, so lane 0 may be off): the first active lane reserves the list range and resets the stage, the active
+// lanes share the copy.  The lanes that are off do not touch the stage meanwhile (they are not executing).
+__device__ __forceinline__ void sel_feed_cand_flush(SelFeed& f) {
   lds_u32* reg = f.hkey + (threadIdx.x >> 6) * f.cand_words;
   const uint32_t cnt = reg[0];
   if (cnt == 0u) return;
+  const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+  const int lane = threadIdx.x & 63, leader = __builtin_ctzll(act);
+  const uint32_t nact = (uint32_t)__builtin_popcountll(act);
+  const uint32_t mine = (uint32_t)__builtin_popcountll(act & ((1ull << lane) - 1ull));  // index among the active lanes
   uint32_t base = 0u;
-  if ((threadIdx.x & 63) == 0) base = atomicAdd(&f.ws->cand_n, cnt);
-  base = __builtin_amdgcn_readfirstlane(base);
-  for (uint32_t i = threadIdx.x & 63; i < cnt; i += 64)
+  if (lane == leader) base = atomicAdd(&f.ws->cand_n, cnt);
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  for (uint32_t i = mine; i < cnt; i += nact)
     if (base + i < (uint32_t)SEL_CAND_MAX) f.ws->br_fine[base + i] = reg[1 + i];
-  if ((threadIdx.x & 63) == 0) reg[0] = 0u;
+  __builtin_amdgcn_wave_barrier();  // (every copy above reads the stage before the count is reset)
+  if (lane == leader) reg[0] = 0u;
 }
 __device__ __forceinline__ void sel_feed_cand_add(SelFeed& f, uint32_t bits) {
   lds_u32* reg = f.hkey + (threadIdx.x >> 6) * f.cand_words;

@@ -85,6 +85,9 @@ def _bind_select():
     return L
 
 
+_merged_hist_checked = False
+
+
 @torch.no_grad()
 def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=None, dtype=None,
                      total: Optional[int] = None, wide: bool = False) -> torch.Tensor:
@@ -150,10 +153,19 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
         if dist_on:
             off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
             L.mq_select_layout(level, ctypes.byref(off), ctypes.byref(cnt))
-            # (bin counts stay far below 2^31 for anything that fits a node)
+            # the uint32 counters travel as int32 (the collectives have no unsigned 32-bit sum): exact while every
+            # summed bin stays below 2^31, i.e. for fewer than 2^31 values in all -- refused above that, and the
+            # first merged histogram of a process is checked once on the host
+            if n >= 1 << 31:
+                raise OverflowError("joint_percentile: 2^31 or more values in one selection across ranks")
             hist = ws[off.value: off.value + 4 * cnt.value].view(torch.int32)
             _drain_for_host_backend(group)
             dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+            global _merged_hist_checked
+            if not _merged_hist_checked:
+                _merged_hist_checked = True
+                if int(hist.min().item()) < 0:
+                    raise OverflowError("joint_percentile: a merged histogram bin passed 2^31")
         _lib.check(L.mq_select_scan(level, k0.value, k1.value, int(level == levels), code, gamma.value,
                                     out.data_ptr(), None, wp, wn, st))
     return out
