@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--numpy-order", action="store_true",
                     help="model sweeps: every mean in numpy's summation order (mse_tensor / mse_rep / mse_p99 in the "
                          "reference's bits); a correctness mode, an order of magnitude slower")
+    ap.add_argument("--dump-table", metavar="PATH", default=None,
+                    help="model sweeps: rank 0 saves the last step's record table and model-wide P99 (numpy .npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the c2 and llama70b_shard results")
     ap.add_argument("--watchdog", type=int, default=None, metavar="SECONDS",
@@ -491,6 +493,14 @@ def main():
     isolated = None
     if sharded or getattr(wl, "sweep", None) is not None:
         isolated = launch_alone(wl, device, dist, world, reserve, local_algo)
+
+    if args.dump_table and sharded and rank == 0:
+        import numpy as np
+        table, p99 = wl.step()
+        torch.cuda.synchronize()
+        np.savez(args.dump_table, table=table.numpy(), p99=p99.numpy(), layers_mine=np.asarray(wl.mine))
+    elif args.dump_table and sharded:
+        wl.step()   # (the collectives of rank 0's extra step need every rank)
 
     # per-rank shares, for the record
     shares = None

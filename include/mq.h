@@ -372,6 +372,9 @@ size_t mq_error_workspace_bytes(int64_t rows, int64_t cols, int32_t want_cols);
  *   abs_err     |a32 - b32| as float32 (onnx_error_cli.py:90-91) or, for float16 inputs, the float16
  *               |h(a - b)| of single_weight_quant_error.py:39-40 and compare.py:104
  * Divide by the vector length on the host side to get the MSEs.  Any output may be NULL.
+ * Sums are added in a fixed order: a call form (the set of outputs requested on one shape) gives the same bits run
+ * after run.  Different call forms may add in different orders -- with col_sse the totals come from the column
+ * pass, without it from the row pass -- so totals agree ACROSS forms to the 1e-6 relative bar, not bit for bit.
  */
 int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,
                    void* abs_err, int32_t abs_err_dtype, double* seg_sse, double* col_sse, double* totals,
@@ -386,7 +389,9 @@ int mq_error_stats(const void* a, const void* b, int32_t dtype, int64_t rows, in
  * without col_sse any shape).  More columns return MQ_ERR_TOO_LARGE before anything is enqueued.  The call makes
  * no hipMalloc / hipFree and calls no allocating routine; the array's address is looked up once per device.  All
  * calls on one GPU share the array: calls that overlap there (different streams, different threads) race; calls
- * on one stream are ordered as usual.  Arguments and results are those of mq_error_stats.
+ * on one stream are ordered as usual.  The GPU that holds the tensors (and owns the stream) must be the calling
+ * thread's current device -- the array used is the current device's copy; a tensor of another GPU returns
+ * MQ_ERR_ARG.  Arguments and results are those of mq_error_stats.
  */
 #define MQ_ERROR_STATS_STATIC_MAX_COLS 8192
 int mq_error_stats_static(const void* a, const void* b, int32_t dtype, int64_t rows, int64_t cols, int64_t seg_len,

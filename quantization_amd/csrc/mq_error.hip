@@ -543,22 +543,36 @@ extern "C" int mq_error_stats(const void* a, const void* b, int32_t dtype, int64
 static const size_t kStaticScratchBytes =
     (size_t)kErrMaxGrid * 2 * sizeof(double) + (size_t)64 * MQ_ERROR_STATS_STATIC_MAX_COLS * sizeof(double);
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+#include <atomic>
 #include <mutex>
 static const int kMaxDevices = 64;
-static void* scratch_ptr[kMaxDevices];  // per device, null until looked up
+static std::atomic<void*> scratch_ptr[kMaxDevices];  // per device, null until looked up
 static std::mutex scratch_mu;
 
-static int static_scratch(void** out) {
+// This device's copy of the array.  The launches go to the CURRENT device, so the tensors must live there: a
+// tensor of another GPU (with its stream) would be paired with this GPU's scratch address.
+static int static_scratch(const void* tensor, void** out) {
   int dev = -1;
   MQ_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices) return MQ_ERR_UNSUPPORTED;
-  std::lock_guard<std::mutex> lock(scratch_mu);
-  if (!scratch_ptr[dev]) {
-    void* q = nullptr;
-    MQ_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)));  // this device's copy of the array
-    scratch_ptr[dev] = q;
+  if (tensor) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, tensor) != hipSuccess) {
+      (void)hipGetLastError();  // (not a pointer HIP knows: the launch itself will say so)
+    } else if (at.type == hipMemoryTypeDevice && at.device != dev) {
+      return MQ_ERR_ARG;
+    }
   }
-  *out = scratch_ptr[dev];
+  void* q = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!q) {
+    std::lock_guard<std::mutex> lock(scratch_mu);
+    q = scratch_ptr[dev].load(std::memory_order_relaxed);
+    if (!q) {
+      MQ_HIP(hipGetSymbolAddress(&q, HIP_SYMBOL(scratch)));  // the current device's copy of the array
+      scratch_ptr[dev].store(q, std::memory_order_release);
+    }
+  }
+  *out = q;
   return MQ_OK;
 }
 
@@ -568,7 +582,7 @@ extern "C" int mq_error_stats_static(const void* a, const void* b, int32_t dtype
   if (rows < 0 || cols < 0) return MQ_ERR_ARG;
   if (col_sse && cols > MQ_ERROR_STATS_STATIC_MAX_COLS) return MQ_ERR_TOO_LARGE;
   void* ws = nullptr;
-  if (int rc = static_scratch(&ws)) return rc;
+  if (int rc = static_scratch(a, &ws)) return rc;
   // (nothing in the array has to start at zero: every slot the finishing kernels read is written by this call)
   return error_stats_impl(a, b, dtype, rows, cols, seg_len, abs_err, abs_err_dtype, seg_sse, col_sse, totals, ws,
                           kStaticScratchBytes, static_cast<hipStream_t>(hip_stream));

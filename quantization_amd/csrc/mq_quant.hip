@@ -81,6 +81,7 @@ struct QuantParams {
                          // the segment's mean squared error float32(sum * (1 / L))
   int32_t seg_exact;     // the float32 entry is summed in numpy's pairwise order instead (k_stats_group<.., true>)
   double* partials;      // [gx][2]
+  float* leaf;           // numpy-order sweeps: the sums of the tensor's 128-element leaves (flattened), or null
   uint32_t bx, gx;       // this workgroup's index among the gx workgroups that share the tensor (blockIdx.x and
                          // gridDim.x, or the tensor's block range of a sweep launch)
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
@@ -114,7 +115,7 @@ struct BatchItem {
 // One pass over tensors of DIFFERENT sizes in one launch (statistics kernels): a one-dimensional grid, tensor i
 // owns the workgroups [blk0, blk0 + nblk) and has its own segment count; the table lives in device memory (any
 // number of tensors; the kernel arguments could not hold it).
-struct SweepItem {  // 64 bytes
+struct SweepItem {  // 80 bytes
   const void* w;
   uint16_t* scale;
   uint16_t* zp;
@@ -122,9 +123,12 @@ struct SweepItem {  // 64 bytes
   double* totals;
   int64_t nseg;
   uint32_t blk0, nblk;
-  int64_t pad;
+  float* leaf;       // numpy-order sweeps: this tensor's 128-element leaf sums (flattened tensor)
+  uint32_t lchunk0;  // ... and the index of its first whole 8192-entry chunk among those of all the pass's lists
+  uint32_t pad;
+  int64_t pad2;
 };
-static_assert(sizeof(SweepItem) == 64, "table entry");
+static_assert(sizeof(SweepItem) == 80, "table entry");
 // numpy's summation of a contiguous run of n float32 values (n a multiple of 8, n <= 32768), unrolled by the host:
 // chunks of 8192 elements (the reduction's inner loop size) added up in order, each chunk summed pairwise -- runs
 // longer than 128 elements are split in two, the left part n / 2 rounded down to a multiple of 8, until the parts
@@ -141,6 +145,7 @@ struct QuantBatch {
   QuantParams common;  // shape, format and flags; pointer fields are filled per tensor
   NumpyProg np;        // SC_STATS_ROWNP only
   const SweepItem* sweep;  // non-null: a sweep launch (sweep_count entries sorted by blk0); item[] is unused
+  const struct NpRowProg* rowprog;  // numpy-order row kernels: the row's summation program (device memory)
   int32_t sweep_count;
   double* sweep_partials;  // [total workgroups][2]
   int64_t ws_stride;   // bytes between the tensors' workspace slices
@@ -169,6 +174,7 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
     p.bx = blockIdx.x - it.blk0;
     p.gx = it.nblk;
     p.partials = b.sweep_partials + 2 * (int64_t)it.blk0;
+    p.leaf = it.leaf;
     p.tred = nullptr; p.sel_ws = nullptr; p.sel_samples = nullptr;
     return p;
   }
@@ -1691,6 +1697,8 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+#include "mq_np.h"
+
 // Runs a post-order program of numpy's split tree (see NumpyProg) over the leaves' sums: bit 0 takes the next leaf's
 // sum, bit 1 adds the two newest partial sums (the older one on the left).  One lane; the stack lives in registers
 // (selected by compare chains, not indexed: an indexed register array would go to scratch memory).
@@ -2318,7 +2326,7 @@ static bool recip_ok_cached(float c) {
 
 #endif  // MQ_PART == 0
 
-#if MQ_PART >= 1
+#if MQ_PART >= 1 && !defined(MQ_NP_UNIT)
 template <int FMT, int NV, int SEL>
 static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
   static_assert(SEL_FEED_THREADS == 256, "the feeding kernels' candidate stages assume four waves per workgroup");
@@ -2427,8 +2435,19 @@ static void launch_fmt(int scope, int nv, int threads, int team_log2, dim3 grid,
 
 #endif  // MQ_PART >= 1
 
+// The numpy-order kernels of one format (their own translation units: MQ_NP_UNIT).
+#if MQ_PART >= 1 && defined(MQ_NP_UNIT)
+#define MQ_CAT2(a, b) a##b
+#define MQ_CAT(a, b) MQ_CAT2(a, b)
+int MQ_CAT(mq_launch_np, MQ_PART)(int bf16, int scope, int nv, int team_log2, dim3 grid, size_t lds_bytes, hipStream_t st,
+                                  const QuantBatch& b) {
+  if (bf16) return launch_np<MQ_PART - 1, true>(scope, nv, team_log2, grid, lds_bytes, st, b);
+  return launch_np<MQ_PART - 1, false>(scope, nv, team_log2, grid, lds_bytes, st, b);
+}
+#endif
+
 // One format's kernels per translation unit.
-#if MQ_PART >= 1
+#if MQ_PART >= 1 && !defined(MQ_NP_UNIT)
 #define MQ_PART_FMT (MQ_PART - 1)  // MQ_INT_SYM, MQ_INT_ASYM, MQ_LUT_FP, MQ_LUT_FP_SUB
 #define MQ_CAT2(a, b) a##b
 #define MQ_CAT(a, b) MQ_CAT2(a, b)
@@ -2446,6 +2465,10 @@ void mq_launch_fmt1(int, int, int, int, int, dim3, size_t, hipStream_t, const Qu
 void mq_launch_fmt2(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 void mq_launch_fmt3(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 void mq_launch_fmt4(int, int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+int mq_launch_np1(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+int mq_launch_np2(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+int mq_launch_np3(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+int mq_launch_np4(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
 // State of the calling thread: a pool of events that is created outside the timed region (mq_profile_reserve, or
@@ -2990,7 +3013,7 @@ extern "C" int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows,
     if (nb < 1) nb = 1;
     if (blocks + nb > 0x7fffffffll) return MQ_ERR_TOO_LARGE;
     t[i] = SweepItem{items[i].w, static_cast<uint16_t*>(o.scale), static_cast<uint16_t*>(o.zero_point), o.seg_sse,
-                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, 0};
+                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, nullptr, 0u, 0u, 0};
     blocks += nb;
   }
   *seg_len = L;
@@ -3046,6 +3069,8 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
+
+#include "mq_np_host.h"
 
 extern "C" size_t mq_tensor_mse_numpy_workspace_bytes(int64_t rows, int64_t cols) {
   const int64_t n = rows * cols;

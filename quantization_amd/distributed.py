@@ -100,7 +100,8 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     the device; otherwise they are agreed on with two small collectives.  wide (float32 tensors): the result
     is np.percentile of the float64 array holding the same values (float32 keys: two histogram levels; float64
     ranks, interpolation and result) -- per-vector MSE lists are float32 means kept in a float64 array by the
-    analysis scripts (quant_error_single_weight.py:74-79)."""
+    analysis scripts (quant_error_single_weight.py:74-79).  No NaN check: a NaN is ranked as the largest value (numpy
+    would return NaN); callers that may hold one test their data themselves."""
     import torch.distributed as dist
     L = _bind_select()
     dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1

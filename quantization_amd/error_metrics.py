@@ -93,7 +93,10 @@ def percentile(x: torch.Tensor, pct: float = 99.0, return_pair: bool = False, na
     _lib.check(st)
     if nan_check:
         # the select orders a NaN above every number; np.percentile returns NaN when the array holds one
-        out = torch.where(torch.isnan(x).any(), torch.full_like(out, float("nan")), out)
+        has_nan = torch.isnan(x).any()
+        out = torch.where(has_nan, torch.full_like(out, float("nan")), out)
+        if pair is not None:   # (the two order statistics were ranked with NaN as the largest value: not numpy's)
+            pair = torch.where(has_nan, torch.full_like(pair, float("nan")), pair)
     return (out, pair) if return_pair else out
 
 
@@ -170,7 +173,8 @@ def percentile_rows(mats: Sequence[torch.Tensor], pct: float = 99.0, wide: bool 
     """np.percentile(row, pct) for every row of every 2-D tensor of `mats` (one dtype; rows contiguous, 16-byte
     aligned, possibly padded: only stride(1) == 1 is required), results concatenated in order.  percentile_multi
     without a tensor object per row: a model sweep selects from hundreds of per-layer lists per pass.  No NaN
-    check (as percentile_multi(nan_check=False))."""
+    check (as percentile_multi(nan_check=False)): a NaN is ranked as the largest value, where np.percentile
+    returns NaN for the whole row -- callers patch rows they know to hold one (a NaN mean)."""
     if not mats:
         raise ValueError("percentile_rows() needs at least one tensor")
     dtype, dev = mats[0].dtype, mats[0].device

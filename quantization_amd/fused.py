@@ -243,6 +243,18 @@ def bind_batch():
         L_.mq_slice_mean_numpy_f32.argtypes = [ctypes.POINTER(vp), i32, i64, i64, i64, ctypes.POINTER(vp), vp]
         L_.mq_slice_sum_numpy_f32.restype = ctypes.c_int
         L_.mq_slice_sum_numpy_f32.argtypes = L_.mq_slice_mean_numpy_f32.argtypes
+        pi64 = ctypes.POINTER(i64)
+        L_.mq_sweep_numpy_table_bytes.restype = sz
+        L_.mq_sweep_numpy_table_bytes.argtypes = [i32]
+        L_.mq_sweep_numpy_prepare.restype = ctypes.c_int
+        L_.mq_sweep_numpy_prepare.argtypes = [ctypes.POINTER(_QuantItem), pi64, pi64, i32, i32, ctypes.POINTER(_lib.QuantCfg),
+                                              vp, vp, sz, pi64, pi64, pi64, pi64]
+        L_.mq_sweep_numpy_run.restype = ctypes.c_int
+        L_.mq_sweep_numpy_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, sz, vp]
+        L_.mq_sweep_numpy_finish_workspace_bytes.restype = sz
+        L_.mq_sweep_numpy_finish_workspace_bytes.argtypes = [i64, i64]
+        L_.mq_sweep_numpy_finish.restype = ctypes.c_int
+        L_.mq_sweep_numpy_finish.argtypes = [vp, i32, i64, vp, i64, i64, vp, vp, vp, sz, vp]
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

@@ -297,6 +297,7 @@ class SweepPlan:
         # numpy_order: float64 [len(passes), len(weights)], the scripts' mse_tensor bit for bit (filled by run())
         self.mse_tensor = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev) if numpy_order else None
         self.ws_bytes = 0
+        self.side_ws_bytes = 0
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
             single_launch = False
@@ -327,7 +328,7 @@ class SweepPlan:
             scl = torch.empty(total, dtype=torch.float16, device=dev) if numpy_order else None
             zpt = torch.empty(total, dtype=torch.float16, device=dev) if numpy_order and fmt == _lib.INT_ASYM else None
 
-            def make_items(poss):
+            def make_items(poss, params=True):
                 items = (_QuantItem * len(poss))()
                 for j, pos in enumerate(poss):
                     items[j].w = self.weights[self.order[pos]].data_ptr()
@@ -336,9 +337,9 @@ class SweepPlan:
                     o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
                     o.seg_sse = ptrs[pos]
                     o.totals = totals.data_ptr() + pos * 16
-                    if scl is not None:
+                    if scl is not None and params:
                         o.scale = scl.data_ptr() + offs[pos] * 2
-                    if zpt is not None:
+                    if zpt is not None and params:
                         o.zero_point = zpt.data_ptr() + offs[pos] * 2
                 return items
 
@@ -351,12 +352,37 @@ class SweepPlan:
             for pos, i in enumerate(self.order):
                 w = self.weights[i]
                 keys.setdefault((w.dtype, w.shape[1] if gs <= 0 else None), []).append(pos)
+            slow_pos = []     # numpy_order: layers whose means come from the per-layer kernels
             for (dtype, _), poss in keys.items():
+                n = len(poss)
+                rows = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[0] for pos in poss])
+                cols = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[1] for pos in poss])
+                if single_launch and gs != -1 and numpy_order and dtype in (torch.float16, torch.bfloat16):
+                    # every mean in numpy's order from ONE bandwidth launch: list entries and the sums of the
+                    # flattened tensors' 128-element leaves; the finishing kernels make mse_tensor and mse_rep of them
+                    nleaves = sum(self.weights[self.order[pos]].numel() // 128 for pos in poss)
+                    leaf = torch.empty(max(64, nleaves), dtype=torch.float32, device=dev)
+                    host = torch.empty(L.mq_sweep_numpy_table_bytes(n), dtype=torch.uint8)
+                    seg_len, blocks, tl, lc = (ctypes.c_int64(0) for _ in range(4))
+                    rc = L.mq_sweep_numpy_prepare(make_items(poss, params=False), rows, cols, n, _DTYPES[dtype],
+                                                  ctypes.byref(cfg), leaf.data_ptr(), host.data_ptr(), host.numel(),
+                                                  ctypes.byref(seg_len), ctypes.byref(blocks), ctypes.byref(tl),
+                                                  ctypes.byref(lc))
+                    if rc == _lib.OK:
+                        widx = torch.tensor([self.order[pos] for pos in poss], dtype=torch.int64, device=dev)
+                        launches.append(("npsweep", host.to(dev), n, seg_len.value, blocks.value, _DTYPES[dtype], leaf,
+                                         tl.value, lc.value, widx,
+                                         torch.empty(n, dtype=torch.float64, device=dev),
+                                         torch.empty(n, dtype=torch.float32, device=dev)))
+                        self.ws_bytes = max(self.ws_bytes, L.mq_sweep_workspace_bytes(blocks.value))
+                        self.side_ws_bytes = max(self.side_ws_bytes,
+                                                 L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
+                        continue
+                    if rc != _lib.ERR_UNSUPPORTED:
+                        _lib.check(rc)
+                slow_pos += poss
                 if single_launch and gs != -1:
                     items = make_items(poss)
-                    n = len(poss)
-                    rows = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[0] for pos in poss])
-                    cols = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[1] for pos in poss])
                     host = torch.empty(L.mq_sweep_table_bytes(n), dtype=torch.uint8)
                     seg_len, blocks = ctypes.c_int64(0), ctypes.c_int64(0)
                     rc = L.mq_sweep_prepare(items, rows, cols, n, _DTYPES[dtype], ctypes.byref(cfg), host.data_ptr(),
@@ -382,8 +408,8 @@ class SweepPlan:
                 params = [(scl[offs[pos]:offs[pos] + ns[pos]],
                            None if zpt is None else zpt[offs[pos]:offs[pos] + ns[pos]]) for pos in range(nl)]
             self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
-                                  ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns)))
-        self.sel_ws_bytes = self.L.mq_percentile_batch_workspace_bytes(min(nl, 64))
+                                  ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns), slow_pos=slow_pos))
+        self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
 
     def lists(self, k: int):
         return self.plan[k]["lists"]
@@ -416,7 +442,10 @@ class SweepPlan:
             for k, ps in enumerate(self.plan):
                 cfg = ps["cfg"]
                 for la in ps["launches"]:
-                    if la[0] == "sweep":
+                    if la[0] == "npsweep":
+                        _lib.check(L.mq_sweep_numpy_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
+                                                        ws.data_ptr(), ws.numel(), main.cuda_stream))
+                    elif la[0] == "sweep":
                         _, tab, n, seg_len, blocks, dt, flag = la
                         _lib.check(L.mq_sweep_run(tab.data_ptr(), n, seg_len, blocks, dt, ctypes.byref(cfg), flag,
                                                   ws.data_ptr(), ws.numel(), main.cuda_stream))
@@ -428,7 +457,7 @@ class SweepPlan:
                 ready.record(main)
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
-                    sws, _ = workspace(dev, self.sel_ws_bytes)
+                    sws, _ = workspace(dev, self.side_ws_bytes)
                     _lib.check(L.mq_percentile_multi(ps["ptrs"], ps["ns"], nl, _lib.F32_AS_F64, self.pct,
                                                      ps["p99"].data_ptr(), None, sws.data_ptr(), sws.numel(),
                                                      side.cuda_stream))
@@ -436,14 +465,29 @@ class SweepPlan:
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
                                                   self.perm.data_ptr(), nl, self.records[k].data_ptr(),
                                                   side.cuda_stream))
-                    if self.numpy_order:   # mse_rep in numpy's bits (the lists in the order of `weights`) ...
-                        self.records[k][:, 3] = numpy_list_means(ps["lists"], side)
-                        # ... and mse_tensor: numpy's float32 summation over each flattened weight
-                        m32 = torch.empty(nl, dtype=torch.float32, device=dev)
-                        for pos, i in enumerate(self.order):
-                            sc, zp = ps["params"][pos]
-                            tensor_mse_numpy(self.weights[i], cfg, sc, zp, m32[pos], side)
-                        self.mse_tensor[k].index_copy_(0, self.perm, m32.double())
+                    if self.numpy_order:
+                        # mse_rep = float(vec.mean()) and mse_tensor = float(np.mean((a32 - b32) ** 2)) in numpy's
+                        # bits: from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
+                        for la in ps["launches"]:
+                            if la[0] != "npsweep":
+                                continue
+                            _, tab, n, seg_len, _, _, leaf, tl, lc, widx, rep, mt = la
+                            _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
+                                                               mt.data_ptr(), rep.data_ptr(), sws.data_ptr(),
+                                                               sws.numel(), side.cuda_stream))
+                            self.records[k][:, 3].index_copy_(0, widx, rep)
+                            self.mse_tensor[k].index_copy_(0, widx, mt.double())
+                        # ... or layer by layer (shapes the numpy-order launch does not take)
+                        slow = ps["slow_pos"]
+                        if slow:
+                            sidx = torch.tensor([self.order[pos] for pos in slow], dtype=torch.int64, device=dev)
+                            self.records[k][:, 3].index_copy_(
+                                0, sidx, numpy_list_means([ps["lists"][self.order[pos]] for pos in slow], side))
+                            m32 = torch.empty(len(slow), dtype=torch.float32, device=dev)
+                            for j, pos in enumerate(slow):
+                                sc, zp = ps["params"][pos]
+                                tensor_mse_numpy(self.weights[self.order[pos]], cfg, sc, zp, m32[j], side)
+                            self.mse_tensor[k].index_copy_(0, sidx, m32.double())
             self._pending = (main, side)
 
     @torch.no_grad()

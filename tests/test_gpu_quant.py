@@ -513,3 +513,46 @@ def test_quant_model_reference_fixture(qa, case):
                 assert list(b.shape) == list(z[f"{key}/{i}/{n}/shape"]), (what, n, "shape")
                 got = b.contiguous().reshape(-1).view(torch.uint8).cpu().numpy()
                 assert np.array_equal(got, z[f"{key}/{i}/{n}/bytes"]), (what, n, "bytes")
+
+
+_SLOW_FEED_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from quantization_amd import _lib
+from quantization_amd.fused import quantize_batch
+g = torch.Generator(device="cuda").manual_seed(12)
+rows, cols, gs = 2048, 4096, 32
+x = torch.randn(1, rows, cols, generator=g, device="cuda")
+chi = sum(torch.randn(1, rows, cols, generator=g, device="cuda") ** 2 for _ in range(3))
+w = (x / torch.sqrt(chi / 3) * 0.02).half()
+# one group in 16 lies on one side of zero with a range below half its offset: |v / s| >= 500, the per-element path;
+# its errors have the size of every other group's, so they fall inside the percentile's bracket
+grp = w.view(-1, gs)
+pick = torch.rand(grp.shape[0], generator=g, device="cuda") < 1 / 16
+pick[0::16] = False                                          # waves whose first lanes are on the fast path ...
+pick[5::64] = True                                           # ... while other lanes of theirs are not
+grp[pick] = grp[pick].abs().clamp(max=0.12) + 0.3
+for pct in (99, 99.9):
+    a = quantize_batch(w, _lib.INT_ASYM, 8, gs, None, abs_err=torch.float32, p99=pct)
+    err = a.abs_err.cpu().numpy().ravel()
+    want = np.float32(np.percentile(err, pct))
+    got = a.abs_p99.cpu().numpy()
+    assert got.tobytes() == np.array([want], np.float32).tobytes(), (pct, got, want)
+print("ok")
+"""
+
+
+def test_fused_p99_wide_bracket_with_per_element_segments():
+    """Heavy-tailed weights (a wide bracket: the values inside it are kept as a list, staged per wave in LDS) with
+    segments on the per-element path scattered among the others, so that the stage is flushed by waves whose first
+    lanes are not taking part.  Eight workgroups (MQ_MAX_BLOCKS, read once per process: hence a child process) make
+    every wave stage more than its area holds.  The P99 must equal np.percentile of the dump."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SLOW_FEED_SCRIPT, root], env=dict(os.environ, MQ_MAX_BLOCKS="8"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -419,3 +419,31 @@ def test_numpy_list_means_have_numpys_bits():
         want = np.array([v.astype(np.float64).mean() for v in lists])
     same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
     assert same.all(), [(lens[i], got[i], want[i]) for i in np.nonzero(~same)[0]]
+
+
+def test_bench_two_ranks_end_to_end(tmp_path):
+    """bench.py --gpus 2 as the driver starts it, with gloo standing in for RCCL (both ranks on this GPU): the run
+    ends with one JSON line that says n_gpus = 2, both shards hold layers, and the merged record table and model-wide
+    P99 of the two ranks equal the one-rank run's bit for bit."""
+    import json
+    import subprocess
+    env = dict(os.environ, MQ_BENCH_BACKEND="gloo")
+    outs = {}
+    for n in (1, 2):
+        path = str(tmp_path / f"table{n}.npz")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+               "--no-extra", "--no-cpu-baseline", "--watchdog", "200", "--dump-table", path]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        outs[n] = (json.loads(line), np.load(path), r.stderr)
+    j2, t2, err2 = outs[2]
+    assert j2["n_gpus"] == 2 and j2["config"]["backend"] == "gloo" and j2["scaling"] == "strong"
+    assert len(j2["config"]["layers_per_rank"]) == 2 and min(j2["config"]["layers_per_rank"]) > 0
+    assert sum(j2["config"]["layers_per_rank"]) == 225
+    assert "rank 0/2" in err2 and "rank 1/2" in err2          # every rank names its shard before the first collective
+    assert j2["config"]["weight_bytes_per_step_whole_job"] == outs[1][0]["config"]["weight_bytes_per_step_whole_job"]
+    t1 = outs[1][1]
+    assert t1["table"].shape == t2["table"].shape == (4 * 225, 6)
+    assert np.array_equal(t1["table"].view(np.int64), t2["table"].view(np.int64))
+    assert t1["p99"].tobytes() == t2["p99"].tobytes()

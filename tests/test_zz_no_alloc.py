@@ -24,8 +24,11 @@ def _call(L, fn, a, b, rows, cols, seg_len, ws=None):
             out["seg_sse"].data_ptr(), out["col_sse"].data_ptr(), out["totals"].data_ptr()]
     if ws is not None:
         args += [ws.data_ptr(), ws.numel()]
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]          # hipMemGetInfo: device memory nobody has allocated
     rc = fn(*args, st)
     torch.cuda.synchronize()
+    out["_allocated"] = free0 - torch.cuda.mem_get_info()[0]
     return rc, out
 
 
@@ -49,6 +52,8 @@ def test_static_entry_point_equals_workspace_entry_point():
         rc0, want = _call(L, L.mq_error_stats, a, b, rows, cols, seg, ws)
         rc1, got = _call(L, L.mq_error_stats_static, a, b, rows, cols, seg)
         assert rc0 == 0 and rc1 == 0, (rc0, rc1)
+        want.pop("_allocated")
+        assert got.pop("_allocated") == 0, "the static entry point took device memory"
         for k in want:
             assert torch.equal(got[k].view(torch.int64 if got[k].dtype == torch.float64 else torch.int32),
                                want[k].view(torch.int64 if want[k].dtype == torch.float64 else torch.int32)), (rows, cols, k)
