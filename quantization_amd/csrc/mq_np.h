@@ -36,7 +36,8 @@ struct NpLeaf {
 // one depth: chunk_leaves[] are powers of two) -- true for every row length that is 128 * 2^k * odd-free ... in
 // practice for the multiples of 128 that models use; the host checks and refuses the others.
 struct NpRowProg {
-  uint32_t nleaves, nrow, nchunks, pad;
+  uint32_t nleaves, nrow, nchunks;
+  uint32_t regular;  // every chunk holds a multiple of 16 leaves: 16 consecutive leaves are a subtree
   uint32_t chunk_leaves[4];
   NpLeaf leaf[MQ_NPL_MAX];
 };
@@ -190,6 +191,15 @@ __device__ __forceinline__ uint32_t np_words_reduce(const uint32_t* w) {
   }
 }
 __device__ __forceinline__ void np_lds_order() { __builtin_amdgcn_wave_barrier(); }
+// float32 values of lanes 0 .. 31 added as a perfect tree, neighbours first; valid in lane 0
+__device__ __forceinline__ float np_wave_tree32(float v) {
+  v += f_from_bits(dpp<DPP_XOR1>(f_bits(v)));
+  v += f_from_bits(dpp<DPP_XOR2>(f_bits(v)));
+  v += f_from_bits(dpp<DPP_HALF_MIRROR>(f_bits(v)));
+  v += f_from_bits(dpp<DPP_MIRROR>(f_bits(v)));
+  v += __shfl_xor(v, 16);
+  return v;
+}
 
 // ---- groups of 32 * T elements, T = 1, 2, 4 -------------------------------------------------------------------
 // A wave step is 4 KiB = 16 leaves of the flattened tensor (the host admits tensors of a multiple of 8192 elements,
@@ -353,12 +363,119 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+// ---- rows of 2048 * S elements, S = 1, 2, 4 ---------------------------------------------------------------------
+// A wave per row: the row is S wave steps of the group kernel (16 leaves each) and at most one chunk of numpy's
+// summation, a perfect tree -- everything after the one LDS exchange stays in registers: the words of all S steps
+// (the row's parameters need them all), the leaf sums, the 16 leaves of a step added by lane shuffles, the S step
+// sums by a small tree.  These rows' leaves ARE the leaves of the flattened tensor.
+template <int FMT, bool BF16, int S>
+__global__ __launch_bounds__(256) void k_np_rowx(const QuantBatch b) {
+  const QuantParams p = batch_params(b);
+  __shared__ double lds[32];
+  __shared__ __attribute__((aligned(16))) uint32_t xch[4][16 * MQ_NP_LEAF_WORDS];
+  const int lane = threadIdx.x & 63, q = lane >> 2, m = lane & 3;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t first = (int64_t)p.bx * 4 + wv, stride = (int64_t)p.gx * 4;
+  uint32_t* reg = xch[wv];
+  const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
+  const uint32_t loff = (uint32_t)lane * 16u;
+  double acc_sse = 0.0, acc_abs = 0.0;
+  float* ent_out = reinterpret_cast<float*>(p.seg_sse);
+  const float row_len = (float)p.L;
+
+  auto issue = [&](int64_t row, u32x4* dst) __attribute__((always_inline)) {
+    const uint32_t base = row < p.nseg ? (uint32_t)(row * (4096 * S)) + loff : MQ_STATS_OOB;
+#pragma unroll
+    for (int j = 0; j < 4 * S; ++j) dst[j] = stats_bload<true>(rs, base + j * 1024);
+  };
+  auto exchange = [&](const u32x4* buf, uint32_t* W) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<u32x4*>(&reg[(4 * j + (lane >> 4)) * MQ_NP_LEAF_WORDS + (lane & 15) * 4]) = buf[j];
+    np_lds_order();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) W[k] = reg[q * MQ_NP_LEAF_WORDS + 4 * k + m];
+    np_lds_order();
+    if constexpr (BF16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) W[k] = bf16x2_to_f16(W[k]);
+    }
+  };
+  u32x4 buf[4 * S];
+  issue(first, buf);
+  for (int64_t row = first; row < p.nseg; row += stride) {
+    uint32_t W[S][16];
+#pragma unroll
+    for (int s = 0; s < S; ++s) exchange(buf + 4 * s, W[s]);
+    issue(row + stride, buf);  // the next row's loads fly while this one is summed (past the last row: nothing)
+    uint32_t red = np_words_reduce<FMT, 16>(W[0]);
+#pragma unroll
+    for (int s = 1; s < S; ++s) red = stats_op<FMT>(red, np_words_reduce<FMT, 16>(W[s]));
+    const SegP sp = stats_params<FMT>(team_reduce_u32<64>(red, stats_op<FMT>), p);
+    const NpSeg g = np_seg<FMT>(sp);
+    float B[S];
+    float ab = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float lo = 0.f, hi = 0.f;
+      if (__builtin_expect(!sp.slow, 1)) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          uint32_t epk;
+          float e0, e1;
+          np_word_fast<FMT>(p, W[s][k], g, epk, e0, e1);
+          np_chain_fast<FMT>(lo, hi, epk, e0, e1);
+          np_abs_fast<FMT>(ab, epk, e0, e1);
+          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {  // the whole row by the per-element routine
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+          uint32_t vw = W[s][0];
+#pragma unroll
+          for (int kk = 1; kk < 16; ++kk) vw = kk == k ? W[s][kk] : vw;
+          float e0, e1;
+          np_word_slow<FMT>(p, vw, g, e0, e1);
+          lo += e0 * e0;
+          hi += e1 * e1;
+          ab += __builtin_fabsf(e0) + __builtin_fabsf(e1);
+        }
+      }
+      const float leaf = np_quad_tree(lo + hi);
+      if (m == 0) {
+        if (p.leaf) p.leaf[(row * S + s) * 16 + q] = leaf;
+        acc_sse += (double)leaf;
+      }
+      float v = leaf;  // the 16 leaves of the step (a quad's four lanes hold the same value)
+      v += f_from_bits(dpp<DPP_HALF_MIRROR>(f_bits(v)));
+      v += f_from_bits(dpp<DPP_MIRROR>(f_bits(v)));
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      B[s] = v;
+    }
+    acc_abs += (double)ab;
+    float total = B[0];
+    if constexpr (S == 2) total = B[0] + B[1];
+    if constexpr (S == 4) total = (B[0] + B[1]) + (B[2] + B[3]);
+    if (lane == 0) {
+      if (ent_out) ent_out[row] = total / row_len;  // np.mean: the float32 sum over the count, rounded once
+      if (p.scale) p.scale[row] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[row] = (uint16_t)h_bits(sp.zp);
+    }
+  }
+  block_partials(p, acc_sse, acc_abs, lds);
+}
+
 // ---- rows ------------------------------------------------------------------------------------------------------
 // WPR waves share a row (1: a wave per row, rows of up to 512 * NV elements; 4: the workgroup per row, up to 2048 *
 // NV).  The row is loaded as in k_stats_row, its parameters come from the lanes' own vectors, then the float16 row
-// goes to LDS and the quads walk the leaves of the row program: the leaves of the row's own tree (their sums are
-// combined level by level in LDS, the chunks' sums added in order, divided as np.mean divides) and the 128-element
-// leaves of the flattened tensor where they are not the same runs.  Rows are a multiple of 128 elements.
+// goes to LDS (the registers are free for the next row's loads at once) and the quads walk the leaves of the row
+// program: first the leaves of the row's own tree, then the 128-element leaves of the flattened tensor that are not
+// among them.  Those read the ERRORS the row leaves left in place of the weights (packed float16, exact), so no
+// element is quantized twice; the tables without subnormals, whose error needs float32, quantize again.
+// The row's tree: 16 consecutive leaves are a subtree whenever every chunk holds a multiple of 16 leaves
+// (prog.regular) -- the 16 quads of a wave add them with lane shuffles, the few block sums meet in LDS; otherwise the
+// leaf sums are combined level by level in LDS.  Then the chunks' sums in order, divided as np.mean divides.
 template <int FMT, bool BF16, int NV, int WPR>
 __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
   const QuantParams p = batch_params(b);
@@ -368,6 +485,7 @@ __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
   __shared__ NpLeaf leaves[MQ_NPL_MAX];
   const NpRowProg& prog = *b.rowprog;
   const int nleaves = (int)prog.nleaves, nrow = (int)prog.nrow;
+  const bool regular = prog.regular != 0;
   for (int i = threadIdx.x; i < nleaves; i += 256) leaves[i] = prog.leaf[i];
   __syncthreads();
   const int lane = threadIdx.x & 63, m = lane & 3;
@@ -389,6 +507,7 @@ __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
   const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
   float* ent_out = reinterpret_cast<float*>(p.seg_sse);
   const float row_len = (float)p.L;
+  constexpr bool KEEP_ERR = FMT != MQ_LUT_FP;  // the row leaves leave packed float16 errors for the flat leaves
 
   auto issue = [&](int64_t row, u32x4* dst) __attribute__((always_inline)) {
     const uint32_t base = row < p.nseg ? (uint32_t)(row * row_bytes) + loff : MQ_STATS_OOB;
@@ -426,7 +545,54 @@ __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
     }
     return stats_params<FMT>(red, p);
   };
-  auto step = [&](int64_t row, const u32x4* buf) __attribute__((always_inline)) {
+  // One leaf: this lane's two chains over its (up to 16) vectors -> the leaf's sum in every lane of the quad.
+  // from_err: the words are errors a row leaf left; keep: leave the errors in place of the words.
+  auto leaf_sum = [&](const NpLeaf L, const NpSeg& g, bool slow, bool from_err, bool keep, float& ab) __attribute__((always_inline)) {
+    float lo = 0.f, hi = 0.f;
+    if (__builtin_expect(!slow, 1)) {
+      // four vectors at a time; a group past the leaf's end is skipped by the whole wave when no quad needs it, and
+      // vectors past the end inside a group are zeros: a zero weight has a zero error on the fast path (asymmetric
+      // rows on one side of zero are not on it) and adds nothing
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        if (kb >= 2 && __builtin_amdgcn_ballot_w64(4 * kb < (int)L.nv) == 0ull) continue;
+        uint32_t W[4];
+        int a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = (int)L.sv + 4 * kb + k;
+          a[k] = (v >> 4) * MQ_NP_LEAF_WORDS + (v & 15) * 4 + m;
+          W[k] = 4 * kb + k < (int)L.nv ? region[a[k]] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t epk = W[k];
+          float e0 = 0.f, e1 = 0.f;
+          if (!(KEEP_ERR && from_err)) np_word_fast<FMT>(p, W[k], g, epk, e0, e1);
+          np_chain_fast<FMT>(lo, hi, epk, e0, e1);
+          np_abs_fast<FMT>(ab, epk, e0, e1);
+          if constexpr (KEEP_ERR) {
+            if (keep && 4 * kb + k < (int)L.nv) region[a[k]] = epk;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < (int)L.nv; ++k) {
+        const int v = (int)L.sv + k;
+        float e0, e1;
+        np_word_slow<FMT>(p, region[(v >> 4) * MQ_NP_LEAF_WORDS + (v & 15) * 4 + m], g, e0, e1);
+        lo += e0 * e0;
+        hi += e1 * e1;
+        ab += __builtin_fabsf(e0) + __builtin_fabsf(e1);
+      }
+    }
+    return np_quad_tree(lo + hi);
+  };
+  u32x4 buf[NV];
+  issue(first, buf);
+  for (int64_t row = first; row < p.nseg; row += stride) {
     SegP sp;
     {
       u32x4 raw[NV];
@@ -440,73 +606,76 @@ __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
           *reinterpret_cast<u32x4*>(&region[(v >> 4) * MQ_NP_LEAF_WORDS + (v & 15) * 4]) = raw[j];
       }
     }
+    issue(row + stride, buf);  // the next row's loads fly while this one is summed (past the last row: nothing)
     group_sync();
     const NpSeg g = np_seg<FMT>(sp);
     const bool slow = sp.slow;  // (uniform over the row's waves)
     float ab_row = 0.f;
-    for (int lf = quad; lf < nleaves; lf += nquads) {
-      const NpLeaf L = leaves[lf];
-      uint32_t W[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int v = (int)L.sv + k;
-        W[k] = k < (int)L.nv ? region[(v >> 4) * MQ_NP_LEAF_WORDS + (v & 15) * 4 + m] : 0u;
-      }
-      float lo = 0.f, hi = 0.f, ab = 0.f;
-      if (__builtin_expect(!slow, 1)) {
-        // (vectors past the leaf's end are zeros: a zero weight has a zero error on the fast path -- asymmetric rows
-        //  on one side of zero are not on it -- and adds nothing)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          uint32_t epk;
-          float e0, e1;
-          np_word_fast<FMT>(p, W[k], g, epk, e0, e1);
-          np_chain_fast<FMT>(lo, hi, epk, e0, e1);
-          np_abs_fast<FMT>(ab, epk, e0, e1);
-          if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll 1
-        for (int k = 0; k < (int)L.nv; ++k) {
-          uint32_t vw = W[0];
-#pragma unroll
-          for (int kk = 1; kk < 16; ++kk) vw = kk == k ? W[kk] : vw;
-          float e0, e1;
-          np_word_slow<FMT>(p, vw, g, e0, e1);
-          lo += e0 * e0;
-          hi += e1 * e1;
-          ab += __builtin_fabsf(e0) + __builtin_fabsf(e1);
-        }
-      }
-      const float leaf = np_quad_tree(lo + hi);
-      if (m == 0) {
-        if (L.kind & 1) lsum[lf] = leaf;
+    // the leaves of the row's own tree
+    for (int base = 0; base < nrow; base += nquads) {
+      const int lf = base + quad;
+      float leaf = 0.f;
+      if (lf < nrow) {
+        const NpLeaf L = leaves[lf];
+        float ab = 0.f;
+        leaf = leaf_sum(L, g, slow, false, L.kind == 1 && !slow, ab);
         if (L.kind & 2) {
-          if (p.leaf) p.leaf[row * nleaf128 + (L.sv >> 4)] = leaf;
-          acc_sse += (double)leaf;
+          ab_row += ab;
+          if (m == 0) {
+            if (p.leaf) p.leaf[row * nleaf128 + (L.sv >> 4)] = leaf;
+            acc_sse += (double)leaf;
+          }
         }
       }
-      if (L.kind & 2) ab_row += ab;
+      if (regular) {
+        // (whole blocks of 16 leaves: a wave either holds one or none)
+        if (base + (WPR == 1 ? 0 : wv * 16) < nrow) {
+          float v = leaf;
+          v += f_from_bits(dpp<DPP_HALF_MIRROR>(f_bits(v)));  // the quads' values are the same in their four lanes
+          v += f_from_bits(dpp<DPP_MIRROR>(f_bits(v)));
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          if (lane == 0) lsum[(base >> 4) + (WPR == 1 ? 0 : wv)] = v;
+        }
+      } else if (lf < nrow && m == 0) {
+        lsum[lf] = leaf;
+      }
+    }
+    group_sync();
+    // the flat leaves that are not row leaves
+    for (int lf = nrow + quad; lf < nleaves; lf += nquads) {
+      const NpLeaf L = leaves[lf];
+      float ab = 0.f;
+      const float leaf = leaf_sum(L, g, slow, !slow, false, ab);
+      ab_row += ab;
+      if (m == 0) {
+        if (p.leaf) p.leaf[row * nleaf128 + (L.sv >> 4)] = leaf;
+        acc_sse += (double)leaf;
+      }
     }
     acc_abs += (double)ab_row;
-    group_sync();
-    // the row's own tree, chunk by chunk: level by level in place (a wave's LDS accesses execute in order: the reads
-    // of a strip come before its writes, and a strip only writes slots no later strip reads), then the chunks'
-    // sums in order
     if (WPR == 1 || wv == 0) {
       float total = 0.f;
       int o = 0;
       for (int c = 0; c < (int)prog.nchunks; ++c) {
         const int nl = (int)prog.chunk_leaves[c];
-        for (int n = nl; n > 1; n >>= 1) {
-          for (int i = lane; i < (n >> 1); i += 64) {
-            const float a = lsum[o + 2 * i] + lsum[o + 2 * i + 1];
+        float cs;
+        if (regular) {  // the chunk's blocks: a perfect tree of at most 32 values (zeros beside them add nothing)
+          const int nb = nl >> 4;
+          cs = np_wave_tree32(lane < nb ? lsum[(o >> 4) + lane] : 0.f);
+        } else {
+          // level by level in place (a wave's LDS accesses execute in order: the reads of a strip come before its
+          // writes, and a strip only writes slots no later strip reads)
+          for (int n = nl; n > 1; n >>= 1) {
+            for (int i = lane; i < (n >> 1); i += 64) {
+              const float a = lsum[o + 2 * i] + lsum[o + 2 * i + 1];
+              np_lds_order();
+              lsum[o + i] = a;
+            }
             np_lds_order();
-            lsum[o + i] = a;
           }
-          np_lds_order();
+          cs = lsum[o];
         }
-        const float cs = lsum[o];
         total = c == 0 ? cs : total + cs;
         o += nl;
       }
@@ -518,26 +687,6 @@ __global__ __launch_bounds__(256) void k_np_row(const QuantBatch b) {
     }
     group_sync();
     parity ^= 1;
-  };
-  if constexpr (NV <= 8) {
-    u32x4 bufa[NV], bufb[NV];
-    int64_t row = first;
-    issue(row, bufa);
-    while (row < p.nseg) {
-      const int64_t r1 = row + stride, r2 = r1 + stride;
-      issue(r1, bufb);
-      step(row, bufa);
-      if (r1 >= p.nseg) break;
-      issue(r2, bufa);
-      step(r1, bufb);
-      row = r2;
-    }
-  } else {
-    for (int64_t row = first; row < p.nseg; row += stride) {
-      u32x4 buf[NV];
-      issue(row, buf);
-      step(row, buf);
-    }
   }
   block_partials(p, acc_sse, acc_abs, lds);
 }
@@ -559,6 +708,12 @@ static int launch_np(int scope, int nv, int team_log2, dim3 grid, size_t lds_byt
       case 0: hipLaunchKernelGGL((k_np_group<FMT, BF16, 1>), grid, dim3(256), 0, st, p); break;
       case 1: hipLaunchKernelGGL((k_np_group<FMT, BF16, 2>), grid, dim3(256), 0, st, p); break;
       default: hipLaunchKernelGGL((k_np_group<FMT, BF16, 4>), grid, dim3(256), 0, st, p); break;
+    }
+  } else if (scope == SC_STATS_ROWNP) {  // rows of 2048 * nv elements
+    switch (nv) {
+      case 1: hipLaunchKernelGGL((k_np_rowx<FMT, BF16, 1>), grid, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((k_np_rowx<FMT, BF16, 2>), grid, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((k_np_rowx<FMT, BF16, 4>), grid, dim3(256), 0, st, p); break;
     }
   } else if (scope == SC_STATS_ROW) {
     switch (nv) {

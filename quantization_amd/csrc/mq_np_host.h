@@ -28,19 +28,47 @@ __global__ __launch_bounds__(256) void k_np_chunk_sums(const float* leaf, int64_
 // per tensor: the sums are staged through LDS 1024 at a time, thread 0 adds.
 __global__ __launch_bounds__(256) void k_np_tensor_finish(const SweepItem* tab, int64_t seg_len, const float* leaf_base,
                                                           const float* cs, float* out) {
-  __shared__ float buf[1024];
+  __shared__ __attribute__((aligned(16))) float buf[2][2048];
   const SweepItem& it = tab[blockIdx.x];
   const int64_t n = it.nseg * seg_len, nchunks = n / 8192;
   const float* mine = cs + (it.leaf - leaf_base) / 64;
   float total = 0.f;
-  for (int64_t base = 0; base < nchunks; base += 1024) {
-    for (int j = threadIdx.x; j < 1024; j += 256) buf[j] = base + j < nchunks ? mine[base + j] : 0.f;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int m = nchunks - base < 1024 ? (int)(nchunks - base) : 1024;
-      for (int j = 0; j < m; ++j) total = (base == 0 && j == 0) ? buf[0] : total + buf[j];
+  // two LDS areas take turns: wave 0's first lane adds the 2048 sums of one while the other waves fetch the next
+  // (the chain of additions is the whole cost: sixteen values per four LDS reads, nothing else in the loop)
+  auto fetch = [&](int64_t base, float* dst) {
+    for (int j = threadIdx.x; j < 2048; j += 256) dst[j] = base + j < nchunks ? mine[base + j] : 0.f;
+  };
+  fetch(0, buf[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t base = 0; base < nchunks; base += 2048) {
+    if (threadIdx.x >= 64) {
+      if (base + 2048 < nchunks) {
+        for (int j = threadIdx.x - 64; j < 2048; j += 192) buf[cur ^ 1][j] = base + 2048 + j < nchunks ? mine[base + 2048 + j] : 0.f;
+      }
+    } else if (threadIdx.x == 0) {
+      const int m = nchunks - base < 2048 ? (int)(nchunks - base) : 2048;
+      const f32x4* b4 = reinterpret_cast<const f32x4*>(buf[cur]);
+      int j = 0;
+      if (base == 0) {  // the first chunk's sum as it is (numpy starts from it, not from zero)
+        const f32x4 a = b4[0];
+        total = a[0];
+        if (m > 1) total += a[1];
+        if (m > 2) total += a[2];
+        if (m > 3) total += a[3];
+        j = 4;
+      }
+      for (; j + 16 <= m; j += 16) {
+        const f32x4 a = b4[j >> 2], c = b4[(j >> 2) + 1], d = b4[(j >> 2) + 2], e = b4[(j >> 2) + 3];
+        total += a[0]; total += a[1]; total += a[2]; total += a[3];
+        total += c[0]; total += c[1]; total += c[2]; total += c[3];
+        total += d[0]; total += d[1]; total += d[2]; total += d[3];
+        total += e[0]; total += e[1]; total += e[2]; total += e[3];
+      }
+      for (; j < m; ++j) total += buf[cur][j];
     }
     __syncthreads();
+    cur ^= 1;
   }
   if (threadIdx.x == 0) out[blockIdx.x] = (float)((double)total / (double)n);
 }
@@ -177,6 +205,9 @@ static bool np_row_prog(int64_t L, NpRowProg* pr) {
   }
   if (!ok) return false;
   pr->nrow = pr->nleaves;
+  pr->regular = 1;
+  for (uint32_t c = 0; c < pr->nchunks; ++c)
+    if (pr->chunk_leaves[c] % 16) pr->regular = 0;
   // the 128-element leaves of the flattened tensor (rows are whole leaves): those that are row leaves too are marked,
   // the others are appended
   for (uint32_t f = 0; f < (uint32_t)(L / 128); ++f) {
@@ -219,6 +250,11 @@ static bool np_scope_build(int64_t L, int* scope, int* nv, int* team_log2, size_
     return true;
   }
   if (!np_row_prog(L, pr)) return false;
+  if (L == 2048 || L == 4096 || L == 8192) {  // a wave per row, all in registers
+    *scope = SC_STATS_ROWNP;
+    *nv = (int)(L / 2048);
+    return true;
+  }
   const int64_t vecs = L / 8;
   int wpr;
   if (vecs <= 512) {

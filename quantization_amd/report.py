@@ -248,7 +248,7 @@ def tensor_mse_numpy(w: torch.Tensor, cfg, scale: torch.Tensor, zero_point: Opti
                                      ws.data_ptr(), ws.numel(), st.cuda_stream))
 
 
-_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+_side_streams: Dict = {}   # device index (and, for the third stream, (index, "fin")) -> stream
 
 
 class SweepPlan:
@@ -298,6 +298,7 @@ class SweepPlan:
         self.mse_tensor = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev) if numpy_order else None
         self.ws_bytes = 0
         self.side_ws_bytes = 0
+        self.fin_ws_bytes = 1 << 16
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
             single_launch = False
@@ -375,8 +376,8 @@ class SweepPlan:
                                          torch.empty(n, dtype=torch.float64, device=dev),
                                          torch.empty(n, dtype=torch.float32, device=dev)))
                         self.ws_bytes = max(self.ws_bytes, L.mq_sweep_workspace_bytes(blocks.value))
-                        self.side_ws_bytes = max(self.side_ws_bytes,
-                                                 L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
+                        self.fin_ws_bytes = max(self.fin_ws_bytes,
+                                                L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
                         continue
                     if rc != _lib.ERR_UNSUPPORTED:
                         _lib.check(rc)
@@ -438,6 +439,12 @@ class SweepPlan:
             if side is None:
                 side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)      # (the previous consumers of the plan's buffers are ordered on `main`)
+            fin = main
+            if self.numpy_order and overlap:
+                fin = _side_streams.get((dev.index, "fin"))
+                if fin is None:
+                    fin = _side_streams[(dev.index, "fin")] = torch.cuda.Stream(device=dev)
+                fin.wait_stream(main)
             ws, _ = workspace(dev, self.ws_bytes)
             for k, ps in enumerate(self.plan):
                 cfg = ps["cfg"]
@@ -465,38 +472,53 @@ class SweepPlan:
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
                                                   self.perm.data_ptr(), nl, self.records[k].data_ptr(),
                                                   side.cuda_stream))
+                    rec_done = None
                     if self.numpy_order:
-                        # mse_rep = float(vec.mean()) and mse_tensor = float(np.mean((a32 - b32) ** 2)) in numpy's
-                        # bits: from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
+                        rec_done = torch.cuda.Event()
+                        rec_done.record(side)
+                if self.numpy_order:
+                    # mse_rep = float(vec.mean()) and mse_tensor = float(np.mean((a32 - b32) ** 2)) in numpy's bits, on a
+                    # THIRD stream: the selections' histogram kernels want a whole compute unit per workgroup and wait
+                    # long for one beside the next pass, while these small workgroups slip in at once -- behind the
+                    # selections they would pile up at the end of the step
+                    with torch.cuda.stream(fin):
+                        fin.wait_event(ready)
+                        fws, _ = workspace(dev, self.fin_ws_bytes)
+                        done = []
+                        # from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
                         for la in ps["launches"]:
                             if la[0] != "npsweep":
                                 continue
                             _, tab, n, seg_len, _, _, leaf, tl, lc, widx, rep, mt = la
                             _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
-                                                               mt.data_ptr(), rep.data_ptr(), sws.data_ptr(),
-                                                               sws.numel(), side.cuda_stream))
-                            self.records[k][:, 3].index_copy_(0, widx, rep)
-                            self.mse_tensor[k].index_copy_(0, widx, mt.double())
+                                                               mt.data_ptr(), rep.data_ptr(), fws.data_ptr(),
+                                                               fws.numel(), fin.cuda_stream))
+                            done.append((widx, rep, mt))
                         # ... or layer by layer (shapes the numpy-order launch does not take)
                         slow = ps["slow_pos"]
                         if slow:
                             sidx = torch.tensor([self.order[pos] for pos in slow], dtype=torch.int64, device=dev)
-                            self.records[k][:, 3].index_copy_(
-                                0, sidx, numpy_list_means([ps["lists"][self.order[pos]] for pos in slow], side))
+                            rep = numpy_list_means([ps["lists"][self.order[pos]] for pos in slow], fin)
                             m32 = torch.empty(len(slow), dtype=torch.float32, device=dev)
                             for j, pos in enumerate(slow):
                                 sc, zp = ps["params"][pos]
-                                tensor_mse_numpy(self.weights[self.order[pos]], cfg, sc, zp, m32[j], side)
-                            self.mse_tensor[k].index_copy_(0, sidx, m32.double())
-            self._pending = (main, side)
+                                tensor_mse_numpy(self.weights[self.order[pos]], cfg, sc, zp, m32[j], fin)
+                            done.append((sidx, rep, m32))
+                        fin.wait_event(rec_done)     # (the pass's record rows are written: now their mse_rep column)
+                        for widx, rep, mt in done:
+                            self.records[k][:, 3].index_copy_(0, widx, rep)
+                            self.mse_tensor[k].index_copy_(0, widx, mt.double())
+            self._pending = (main, side, fin)
 
     @torch.no_grad()
     def finish(self) -> torch.Tensor:
         """Joins the second stream into the one launch() ran on and returns the records (ordered on that stream)."""
-        main, side = self._pending
+        main, side, fin = self._pending
         self._pending = None
         if side is not main:
             main.wait_stream(side)
+        if fin is not main:
+            main.wait_stream(fin)
         return self.records
 
 
