@@ -188,6 +188,38 @@ int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t 
                  const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
 /*
+ * The same pass with every number of a report row in numpy's bits, at the speed of the pass above: per tensor
+ *   the float32 per-vector list   per_vec[i] = compute_mse(slice)       quant_error_single_weight.py:56-71
+ *   mse_tensor = float(np.mean((a32 - b32) ** 2)), float32              quant_error_multi_weight.py:55-58
+ *   mse_rep    = float(vec.mean()), vec the float64 array of the list    quant_error_single_weight.py:74-78
+ * (mse_p99 is mq_percentile_multi over the lists, dtype MQ_F32_AS_F64.)  numpy sums pairwise: chunks of 8192
+ * elements added in order, each chunk split down to leaves of at most 128 elements, a leaf by eight strided
+ * accumulators.  The launch runs the leaves' accumulator chains in that order while it streams the weights and writes
+ * the list entries and the sums of the 128-element leaves of every FLATTENED tensor (leaf_sums, one float per 128
+ * weights: the caller provides sum(rows[i] * cols[i]) / 128 floats, 256-byte aligned; tensor i's leaves follow tensor
+ * i - 1's); mq_sweep_numpy_finish turns leaf sums and lists into mse_tensor[count] and mse_rep[count] (table order)
+ * with a few small launches that may run on another stream once the pass has finished.
+ * Taken: float16 / bfloat16 weights of a multiple of 8192 elements, groups of 32 / 64 / 128 elements, or segments
+ * (rows, longer groups) of a multiple of 128 and at most 32768 elements whose chunks split into leaves of one depth
+ * (every multiple of 128 that model shapes use).  Every item requests seg_sse (the float32 list, 16-byte aligned) and
+ * totals, optionally scale / zero_point, none of deq / codes / abs_err.  MQ_ERR_UNSUPPORTED otherwise: use
+ * mq_sweep_run / mq_quantize_batch with seg_mse_f32 = 2, mq_tensor_mse_numpy and mq_list_mean_numpy.
+ * prepare writes mq_sweep_numpy_table_bytes(count) bytes of HOST memory (copy them to the device once) and reports
+ * the launch's workgroups, the number of leaf sums and the number of whole 8192-entry chunks of the lists;
+ * run: workspace of mq_sweep_workspace_bytes(total_blocks) bytes; finish: mq_sweep_numpy_finish_workspace_bytes.
+ */
+size_t mq_sweep_numpy_table_bytes(int32_t count);
+int mq_sweep_numpy_prepare(const mq_quant_item* items, const int64_t* rows, const int64_t* cols, int32_t count,
+                           int32_t w_dtype, const mq_quant_cfg* cfg, float* leaf_sums, void* table_host,
+                           size_t table_bytes, int64_t* seg_len, int64_t* total_blocks, int64_t* total_leaves,
+                           int64_t* list_chunks);
+int mq_sweep_numpy_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
+                       const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
+size_t mq_sweep_numpy_finish_workspace_bytes(int64_t total_leaves, int64_t list_chunks);
+int mq_sweep_numpy_finish(const void* table_dev, int32_t count, int64_t seg_len, const float* leaf_sums,
+                          int64_t total_leaves, int64_t list_chunks, float* mse_tensor, double* mse_rep,
+                          void* workspace, size_t workspace_bytes, void* hip_stream);
+/*
  * mse_tensor in numpy's bits: mse_out[0] = float32 np.mean((a32 - b32) ** 2) over the whole [rows, cols] tensor
  * (compute_mse, quant_error_multi_weight.py:55-58), a32 the float16-rounded weight and b32 its dequantized value:
  * the float32 squares summed in numpy's order over the FLATTENED tensor -- chunks of 8192 elements added in order,

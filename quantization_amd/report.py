@@ -523,23 +523,56 @@ class SweepPlan:
 
 
 @torch.no_grad()
-def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = None):
+def numpy_order_available(weights, passes) -> bool:
+    """Can every pass over these weights be summed in numpy's order (SweepPlan(numpy_order=True))?  float16 / bfloat16
+    weights, per-channel or per-group passes (not per-tensor), segments of a multiple of 8 and at most 32768
+    elements."""
+    for w in weights:
+        if w.dtype not in (torch.float16, torch.bfloat16):
+            return False
+    for _, _, gs in passes:
+        if gs == -1:
+            return False
+        for w in weights:
+            L = gs if (gs is not None and gs > 0) else w.shape[1]
+            if L % 8 or L > 32768 or w.shape[1] % L:
+                return False
+    return True
+
+
+@torch.no_grad()
+def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = None, numpy_order: Optional[bool] = None,
+                return_mse_tensor: bool = False):
     """model_records(weights, datatype, bits, group_size, abs_p99=False) for every (datatype, bits, group_size) of
     `passes`, one shot: float64 [len(passes), len(weights), len(RECORD_FIELDS)] (and, with vecs_of = k, the
-    per-vector MSE lists of pass k).  Builds a SweepPlan and runs it once; keep the plan to sweep the same
-    resident weights repeatedly."""
-    plan = SweepPlan(weights, passes, pct)
+    per-vector MSE lists of pass k; with return_mse_tensor the tensor means [len(passes), len(weights)]).  Builds a
+    SweepPlan and runs it once; keep the plan to sweep the same resident weights repeatedly.
+
+    numpy_order (default: on wherever the kernels offer it, numpy_order_available): mse_rep, mse_p99 and the tensor
+    means have the BITS of the reference's report rows (quant_error_multi_weight.py:55-58, quant_error_single_weight
+    .py:74-79); False: float64 sums, equal to those to the 1e-6 bar on small tensors and a few 1e-6 away on whole
+    LLM weights, where numpy's float32 sums drift."""
+    weights, passes = list(weights), list(passes)
+    if numpy_order is None:
+        numpy_order = numpy_order_available(weights, passes)
+    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order)
     out = plan.run()
-    return (out, plan.lists(vecs_of)) if vecs_of is not None else out
+    res = [out]
+    if vecs_of is not None:
+        res.append(plan.lists(vecs_of))
+    if return_mse_tensor:
+        res.append(plan.mse_tensor if numpy_order else out[:, :, 1] / out[:, :, 0])
+    return tuple(res) if len(res) > 1 else out
 
 
 def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", device=None,
-                 numpy_order: bool = False) -> List[Dict]:
+                 numpy_order: bool = True) -> List[Dict]:
     """main() of MSE&P99/quant_error_multi_weight.py:119-164 on two ONNX files, without the `onnx` package and
     with the arithmetic on the device: for every MatMul / Gemm weight of the baseline model that the quantized
     model also holds, float32 cast, tensor MSE, per-vector MSE list (form="multi": columns / column blocks as
     that script; form="single": rows / (row, group) as quant_error_single_weight.py), its mean and P99.
-    numpy_order: every mean in numpy's summation order -- the script's numbers bit for bit (compute_errors).
+    numpy_order (the default: this is the report path): every mean in numpy's summation order -- the script's
+    numbers bit for bit (compute_errors); False: float64 sums in one pass, equal to those to 1e-6.
     Returns the CSV rows (write them with write_csv)."""
     from .error_metrics import compute_errors
     from .onnx_io import OnnxWeights
@@ -561,7 +594,7 @@ def compare_onnx(baseline_model: str, quant_model: str, form: str = "multi", dev
 
 
 def compare_onnx_single(baseline_model: str, quant_models: Iterable[str], initializer: str, bins: int = 50,
-                        device=None, numpy_order: bool = False):
+                        device=None, numpy_order: bool = True):
     """main() of MSE&P99/quant_error_single_weight.py:85-140 for one initializer of the baseline model and several
     quantized models: one CSV row per quantized model (tensor MSE; mean and P99 of the per-row / per-(row, group)
     MSE list) and, in place of the script's plt.hist(vec, bins=50) calls (:118-124), each list's np.histogram

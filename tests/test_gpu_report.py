@@ -343,12 +343,21 @@ def test_model_sweep_equals_model_records():
     ws = [(torch.randn(*s, generator=g, device="cuda") * 0.02).bfloat16() for s in shapes]
     passes = [("int8", 8, None), ("int8", 8, 32), ("int8_asym", 8, 128), ("fp8_e4m3", 8, 64), ("int8", 8, 128)]
     for _ in range(3):
-        got, vecs = report.model_sweep(ws, passes, vecs_of=1)
+        got, vecs = report.model_sweep(ws, passes, vecs_of=1, numpy_order=False)
         for k, (dt, bits, gs) in enumerate(passes):
             want, wv = report.model_records(ws, dt, bits, gs, abs_p99=False, return_vecs=True)
             assert torch.equal(got[k].view(torch.int64), want.view(torch.int64)), (dt, gs)
             if k == 1:
                 assert all(torch.equal(a, b) for a, b in zip(vecs, wv))
+    # the default is numpy's summation order wherever the kernels offer it: the numbers of the reference's CSV rows
+    assert report.numpy_order_available(ws, passes)
+    got, mt = report.model_sweep(ws, passes, return_mse_tensor=True)
+    plan = report.SweepPlan(ws, passes, numpy_order=True)
+    want = plan.run()
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))
+    assert torch.equal(mt.view(torch.int64), plan.mse_tensor.view(torch.int64))
+    assert not report.numpy_order_available([w.float() for w in ws], passes)
+    assert not report.numpy_order_available(ws, [("int8", 8, -1)])
     torch.cuda.synchronize()
 
 
@@ -391,15 +400,25 @@ def test_single_launch_sweep_equals_per_shape_batches():
                     x, y = a[k][:, col], b[k][:, col]
                     same = (x == y) | (x.isnan() & y.isnan()) | ((x - y).abs() <= 1e-13 * y.abs())
                     assert bool(same.all()), (passes[k], col)
-    # numpy-order entries through the sweep form
+    # numpy-order entries through the sweep forms: the numpy-order launch (tensors of whole 8192-element chunks: list
+    # entries, mse_rep and mse_tensor from the leaf chains of k_np_*) and, with one tensor that is not, the older
+    # form (mq_sweep_run with entries in numpy's order, means layer by layer) -- both against the per-shape batches
     bf = [w.bfloat16() for w in ws]
-    for gs in (32, 64, 128):
-        one = report.SweepPlan(bf, [("int8", 8, gs)], numpy_order=True)
-        per = report.SweepPlan(bf, [("int8", 8, gs)], numpy_order=True, single_launch=False)
-        assert one.plan[0]["launches"][0][0] == "sweep"
-        a, b = one.run().clone(), per.run().clone()
-        assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(one.lists(0), per.lists(0)))
-        assert torch.equal(a[0][:, 4].view(torch.int64), b[0][:, 4].view(torch.int64))
+    odd = (torch.randn(10, 1152, generator=g, device="cuda") * 0.02).bfloat16()
+    for gs in (32, 64, 128, None):
+        for weights, kind in ((bf, "npsweep"), (bf + [odd], "sweep")):
+            if gs is None and kind == "sweep":
+                continue
+            one = report.SweepPlan(weights, [("int8", 8, gs)], numpy_order=True)
+            per = report.SweepPlan(weights, [("int8", 8, gs)], numpy_order=True, single_launch=False)
+            assert {la[0] for la in one.plan[0]["launches"]} == {kind}, (gs, kind)
+            a, b = one.run().clone(), per.run().clone()
+            assert all(torch.equal(x.view(torch.int32), y.view(torch.int32)) for x, y in zip(one.lists(0), per.lists(0)))
+            for col in (3, 4):   # mse_rep, mse_p99
+                x, y = a[0][:, col], b[0][:, col]
+                assert bool(((x.view(torch.int64) == y.view(torch.int64)) | (x.isnan() & y.isnan())).all()), (gs, kind, col)
+            x, y = one.mse_tensor[0], per.mse_tensor[0]
+            assert bool(((x == y) | (x.isnan() & y.isnan())).all()), (gs, kind, "mse_tensor")
     torch.cuda.synchronize()
 
 

@@ -141,7 +141,7 @@ def test_compare_onnx_on_the_reference_quantized_exports(io, oracle):
             continue
         qpath = os.path.join(gold, *name.split("/")) + ".onnx"
         grouping, dtype, bits, gs = report.parse_quant_config(qpath)
-        rows = report.compare_onnx(base, qpath, form="multi")
+        rows = report.compare_onnx(base, qpath, form="multi", numpy_order=False)
         assert sorted(r["initializer"] for r in rows) == m["matmul_gemm_weights"]
         for r in rows:
             a = params[f"block_f16/{r['initializer']}"].view(np.float16).astype(np.float32)
@@ -150,8 +150,8 @@ def test_compare_onnx_on_the_reference_quantized_exports(io, oracle):
             assert (r["datatype"], r["granularity"], r["bits"]) == (dtype, grouping, bits)
             for k in ("mse_tensor", "mse_rep", "mse_p99"):
                 assert abs(r[k] - want[k]) <= 1e-6 * abs(want[k]), (name, r["initializer"], k)
-        # numpy_order: the rows the script itself would write, to the last bit
-        for r in report.compare_onnx(base, qpath, form="multi", numpy_order=True):
+        # numpy_order (the default): the rows the script itself would write, to the last bit
+        for r in report.compare_onnx(base, qpath, form="multi"):
             a = params[f"block_f16/{r['initializer']}"].view(np.float16).astype(np.float32)
             b = params[f"{name}/{r['initializer']}"].view(np.float16).astype(np.float32)
             want = oracle.compute_errors_multi(a, b, grouping, gs)
