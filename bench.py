@@ -89,6 +89,19 @@ def spawn_ranks(args):
     return subprocess.call(cmd)
 
 
+def store_host(dst, src):
+    """Small device tensors -> pinned host tensors with one kernel on the current stream (mq_store_host)."""
+    import torch
+    from quantization_amd import _lib
+    L = _lib.lib()
+    n = len(dst)
+    src = [s.contiguous() for s in src]
+    vp = ctypes.c_void_p
+    _lib.check(L.mq_store_host((vp * n)(*[d.data_ptr() for d in dst]), (vp * n)(*[s.data_ptr() for s in src]),
+                               (ctypes.c_size_t * n)(*[s.numel() * s.element_size() for s in src]), n,
+                               vp(torch.cuda.current_stream().cuda_stream)))
+
+
 def algorithmic_bytes_per_elem(in_bytes, lut, asym, gs, outputs):
     """HBM bytes one fused launch must move per weight element: input once, plus each requested output."""
     import torch
@@ -186,8 +199,7 @@ class ModelSweep:
         if self.host_table is None:
             self.host_table = torch.empty(table.shape, dtype=table.dtype, pin_memory=True)
             self.host_p99 = torch.empty((), dtype=model_p99.dtype, pin_memory=True)
-        self.host_table.copy_(table, non_blocking=True)
-        self.host_p99.copy_(model_p99, non_blocking=True)
+        store_host([self.host_table, self.host_p99], [table, model_p99])
         return self.host_table, self.host_p99
 
 
@@ -331,7 +343,7 @@ class Workload:
         import torch
         if self.host_rec is None:
             self.host_rec = torch.empty(rec.shape, dtype=rec.dtype, pin_memory=True)
-        self.host_rec.copy_(rec, non_blocking=True)
+        store_host([self.host_rec], [rec])
         return self.host_rec
 
 

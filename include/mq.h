@@ -93,6 +93,15 @@ typedef struct {
 } mq_quant_out;
 
 int mq_version(void);
+/*
+ * Up to four small device buffers (multiples of 4 bytes) stored into page-locked host memory by ONE kernel on the
+ * caller's stream: how the statistics of a sweep (a record table of tens of KiB, a percentile) reach the host
+ * inside a step -- the place of the scripts' float(...) conversions (quant_error_multi_weight.py:57-58, :84-86).
+ * dst_host[i]: host memory the device can address (hipHostMalloc, torch pinned memory), readable by the host once
+ * the stream has been synchronised.  No counterpart in the reference (its arrays never leave the host).
+ */
+int mq_store_host(void* const* dst_host, const void* const* src_device, const size_t* bytes, int32_t count,
+                  void* hip_stream);
 const char* mq_strerror(int status);
 /* Text of the last HIP error seen by this thread ("" if none). */
 const char* mq_last_hip_error(void);

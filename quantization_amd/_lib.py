@@ -59,6 +59,8 @@ def lib():
         L.mq_last_hip_error.restype = ctypes.c_char_p
         L.mq_quantize_workspace_bytes.restype = sz
         L.mq_quantize_workspace_bytes.argtypes = [i64, i64, ctypes.POINTER(QuantCfg)]
+        L.mq_store_host.restype = ctypes.c_int
+        L.mq_store_host.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(sz), i32, vp]
         L.mq_profile_reserve.restype = ctypes.c_int
         L.mq_profile_reserve.argtypes = [i64]
         L.mq_profile_begin.restype = ctypes.c_int
