@@ -43,6 +43,8 @@ enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3,
 // element-sized output (deq / codes / abs_err all absent: the sweeps that only want the error statistics), which
 // drops the per-vector tests of the output pointers and everything that only served the stores.
 enum { SEL_STATS_ONLY = 3 };
+enum { LIST_OFF = 0, LIST_SAMPLE = 1, LIST_FEED = 2, LIST_REPAIR = 3 };
+#define LIST_STAGE_CAP 4096  // in-bracket entries a workgroup can stage (it sees at most ~2100 entries at 128 KiB)
 #define SEL_FEEDS(S) ((S) == SEL_FEED_SAMPLE || (S) == SEL_FEED_COUNT)
 #define SEL_STORES(S) ((S) == SEL_FEED_OFF || (S) == SEL_FEED_COUNT)  // may have element-sized outputs
 
@@ -82,6 +84,13 @@ struct QuantParams {
   int32_t seg_exact;     // the float32 entry is summed in numpy's pairwise order instead (k_stats_group<.., true>)
   double* partials;      // [gx][2]
   float* leaf;           // numpy-order sweeps: the sums of the tensor's 128-element leaves (flattened), or null
+  // sweeps that select a list's percentile inside the pass (see mq_sel.h, ListFeedState):
+  int32_t list_mode;     // LIST_OFF / LIST_SAMPLE (the sampling launch) / LIST_FEED (the pass) / LIST_REPAIR
+  ListFeedState* feed;   // this tensor's feed state, or null: its list is written as always
+  float* cand;           // ... its candidate list
+  uint32_t ccap;
+  float* sample;         // sampling launch: where this tensor's sample entries go (null: not sampled)
+  uint32_t sunit, scount;  // one wave step of every sunit is sampled, scount of them
   uint32_t bx, gx;       // this workgroup's index among the gx workgroups that share the tensor (blockIdx.x and
                          // gridDim.x, or the tensor's block range of a sweep launch)
   const uint32_t* tred;  // SC_TENSOR: reduction words written by k_tensor_reduce
@@ -115,7 +124,7 @@ struct BatchItem {
 // One pass over tensors of DIFFERENT sizes in one launch (statistics kernels): a one-dimensional grid, tensor i
 // owns the workgroups [blk0, blk0 + nblk) and has its own segment count; the table lives in device memory (any
 // number of tensors; the kernel arguments could not hold it).
-struct SweepItem {  // 80 bytes
+struct SweepItem {  // 104 bytes
   const void* w;
   uint16_t* scale;
   uint16_t* zp;
@@ -125,10 +134,13 @@ struct SweepItem {  // 80 bytes
   uint32_t blk0, nblk;
   float* leaf;       // numpy-order sweeps: this tensor's 128-element leaf sums (flattened tensor)
   uint32_t lchunk0;  // ... and the index of its first whole 8192-entry chunk among those of all the pass's lists
-  uint32_t pad;
-  int64_t pad2;
+  uint32_t ccap;     // fed lists: capacity of the candidate list
+  ListFeedState* feed;  // fed lists: this tensor's state (null: the list is written), its candidate list, its samples
+  float* cand;
+  float* sample;
+  uint32_t sunit, scount;
 };
-static_assert(sizeof(SweepItem) == 80, "table entry");
+static_assert(sizeof(SweepItem) == 104, "table entry");
 // numpy's summation of a contiguous run of n float32 values (n a multiple of 8, n <= 32768), unrolled by the host:
 // chunks of 8192 elements (the reduction's inner loop size) added up in order, each chunk summed pairwise -- runs
 // longer than 128 elements are split in two, the left part n / 2 rounded down to a multiple of 8, until the parts
@@ -175,6 +187,7 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
     p.gx = it.nblk;
     p.partials = b.sweep_partials + 2 * (int64_t)it.blk0;
     p.leaf = it.leaf;
+    p.feed = it.feed; p.cand = it.cand; p.ccap = it.ccap; p.sample = it.sample; p.sunit = it.sunit; p.scount = it.scount;
     p.tred = nullptr; p.sel_ws = nullptr; p.sel_samples = nullptr;
     return p;
   }
@@ -1425,7 +1438,29 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   const int lane = threadIdx.x & 63, tl = lane & (T - 1), team = lane / T;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t gw = (int64_t)p.bx * 4 + wv, nwaves = (int64_t)p.gx * 4;
-  const int64_t full = p.nseg / SPW, steps = (p.nseg + SPW - 1) / SPW;
+  // The percentile of a large tensor's list is selected inside the pass (mq_sel.h, ListFeedState): the sampling
+  // launch walks one pseudo-randomly chosen whole step of every p.sunit and stores those entries densely; the pass
+  // itself counts the entries under the tensor's bracket and keeps the bit patterns inside it instead of writing
+  // the list; the repair launch writes the list of a tensor whose bracket missed.  (Uniform over the workgroup.)
+  const int list_mode = EXACT ? (int)LIST_OFF : p.list_mode;
+  if (list_mode == LIST_SAMPLE && !p.sample) return;
+  if (list_mode == LIST_REPAIR && !(p.feed && p.feed->miss)) return;
+  const bool sampling = list_mode == LIST_SAMPLE;
+  const bool feeding = list_mode == LIST_FEED && p.feed != nullptr;
+  const uint32_t blo = feeding ? p.feed->blo : 0u, bhi = feeding ? p.feed->bhi : 0u;
+  __shared__ uint32_t stage_n, stage_below;
+  __shared__ uint32_t stage[EXACT ? 1 : LIST_STAGE_CAP];
+  uint32_t nbelow = 0;
+  if (feeding) {
+    if (threadIdx.x == 0) { stage_n = 0; stage_below = 0; }
+    __syncthreads();
+  }
+  const int64_t full = sampling ? (int64_t)p.scount : p.nseg / SPW;
+  const int64_t steps = sampling ? (int64_t)p.scount : (p.nseg + SPW - 1) / SPW;
+  // the wave step behind loop index t: itself, or -- sampling -- the chosen step of unit t
+  auto step_of = [&](int64_t t) __attribute__((always_inline)) {
+    return sampling ? t * (int64_t)p.sunit + (int64_t)(((uint32_t)t * 0x9E3779B1u >> 8) % p.sunit) : t;
+  };
   const char* wb = static_cast<const char*>(p.w);
   // A lane ends up holding the 64-byte run `lane` of the step's 4 KiB (four vectors of one segment; a team is T
   // consecutive runs).  Loaded that way, each load instruction would touch all 32 cache lines of the 4 KiB and
@@ -1443,7 +1478,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
   // the wave's 4 KiB of step t, untransposed; zeros for runs past the last segment and for a step past the last one
   auto issue = [&](int64_t t, u32x4* dst) __attribute__((always_inline)) {
-    const uint32_t base = (uint32_t)(t * 4096) + loff;
+    const uint32_t base = (uint32_t)(step_of(t) * 4096) + loff;
     if constexpr (!TR) {
       const bool in = t < full || t * SPW + team < p.nseg;
 #pragma unroll
@@ -1481,6 +1516,24 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
         // np.mean: the pairwise float32 sum divided by the count, a power of two here (exact)
         const float entry = numpy_entry<(T <= 4 ? T : 1)>(sq) * (float)p.seg_mse_scale;
         if (valid && tl == T - 1) reinterpret_cast<float*>(p.seg_sse)[seg] = entry;
+      }
+    } else if (sampling) {
+      s = team_sum<T>(s);
+      if (valid && tl == 0) p.sample[seg] = (float)(s * p.seg_mse_scale);  // (seg: the dense sample index here)
+      return;
+    } else if (feeding) {
+      s = team_sum<T>(s);
+      const uint32_t bits = f_bits((float)(s * p.seg_mse_scale));  // the entry store_seg would write
+      const bool mine = valid && tl == 0;
+      nbelow += (mine && bits < blo) ? 1u : 0u;
+      const bool inb = mine && bits >= blo && bits <= bhi;        // (a NaN entry lies above every bracket)
+      const unsigned long long mask = __builtin_amdgcn_ballot_w64(inb);
+      if (mask) {
+        const int leader = __builtin_ctzll(mask);
+        uint32_t at = 0u;
+        if (lane == leader) at = atomicAdd(&stage_n, (uint32_t)__builtin_popcountll(mask));
+        at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader) + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (inb && at < (uint32_t)LIST_STAGE_CAP) stage[at] = bits;
       }
     } else if (p.seg_sse) {
       s = team_sum<T>(s);
@@ -1545,11 +1598,32 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
           for (int i = 0; i < 8; ++i) sq[j][i] = 0.f;
       }
       if (sp.slow)
-        stats_slow_segment<FMT>(p, sp, wb + t * 4096 + (TR ? lane * 64 : (int)loff),
+        stats_slow_segment<FMT>(p, sp, wb + step_of(t) * 4096 + (TR ? lane * 64 : (int)loff),
                                 (t < full || t * SPW + team < p.nseg) ? NV : 0, TR ? 16 : 16 * T, s, ab,
                                 EXACT ? sq : nullptr);
       finish(t, sp, s, ab, sp.slow, sq);
     }
+  }
+  if constexpr (!EXACT) {
+    if (feeding) {  // the workgroup's count and kept entries -> the tensor's
+      for (int off = 32; off > 0; off >>= 1) nbelow += __shfl_xor(nbelow, off);
+      if (lane == 0 && nbelow) atomicAdd(&stage_below, nbelow);
+      __syncthreads();
+      __shared__ uint32_t gbase;
+      const uint32_t cnt = stage_n;
+      if (threadIdx.x == 0) {
+        if (stage_below) atomicAdd(&p.feed->below, stage_below);
+        gbase = cnt ? atomicAdd(&p.feed->cand_n, cnt) : 0u;
+        if (cnt > (uint32_t)LIST_STAGE_CAP) p.feed->ovf = 1u;
+      }
+      __syncthreads();
+      const uint32_t g0 = gbase, m = cnt < (uint32_t)LIST_STAGE_CAP ? cnt : (uint32_t)LIST_STAGE_CAP;
+      uint32_t* cand = reinterpret_cast<uint32_t*>(p.cand);
+      for (uint32_t i = threadIdx.x; i < m; i += 256)
+        if (g0 + i < p.ccap) cand[g0 + i] = stage[i];
+    }
+    // (the sampling and repair launches run beside another pass: its partial sums are not theirs to write)
+    if (list_mode == LIST_SAMPLE || list_mode == LIST_REPAIR) return;
   }
   block_partials(p, acc_sse, acc_abs, lds);
 }
@@ -3013,7 +3087,7 @@ extern "C" int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows,
     if (nb < 1) nb = 1;
     if (blocks + nb > 0x7fffffffll) return MQ_ERR_TOO_LARGE;
     t[i] = SweepItem{items[i].w, static_cast<uint16_t*>(o.scale), static_cast<uint16_t*>(o.zero_point), o.seg_sse,
-                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, nullptr, 0u, 0u, 0};
+                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, nullptr, 0u, 0u, nullptr, nullptr, nullptr, 0u, 0u};
     blocks += nb;
   }
   *seg_len = L;
@@ -3070,6 +3144,7 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
   return MQ_OK;
 }
 
+#include "mq_feed_host.h"
 #include "mq_np_host.h"
 
 extern "C" size_t mq_tensor_mse_numpy_workspace_bytes(int64_t rows, int64_t cols) {

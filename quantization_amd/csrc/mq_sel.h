@@ -79,6 +79,40 @@ int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sampl
                      double pct, hipStream_t st);
 int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st);
 
+// ---- percentile of a per-vector MSE list selected inside the statistics pass (sweep launches) -----------------
+// The list of a large tensor is not written: a sampling launch evaluates one wave step of every `unit` steps and
+// stores those entries, k_list_bracket takes two sample ranks a safe margin either side of the wanted quantile as
+// the bracket [blo, bhi] (float32 bit patterns, inclusive), the pass counts the entries under the bracket and keeps
+// the bit patterns inside it (ListFeedState, candidate list), k_list_cand selects the wanted ranks among those.
+// The counts are exact: the sample only decides where to look.  A bracket that does not hold both ranks (or a
+// candidate list that overflowed) sets `miss`; the repair launches then write that tensor's list after all and
+// select from it.
+struct ListFeedState {  // one per fed tensor, device memory; cleared before the sampling launch
+  uint32_t blo, bhi;    // written by k_list_bracket
+  uint32_t below;       // entries under the bracket          (statistics pass)
+  uint32_t cand_n;      // entries inside it, may pass ccap   (statistics pass)
+  uint32_t ovf;         // a workgroup's stage overflowed     (statistics pass)
+  uint32_t miss;        // written by k_list_cand
+  uint32_t pad[2];
+};
+struct ListJob {        // one per fed tensor, device memory, written by the host when the sweep is planned
+  const float* samples; // sample entries
+  const float* cand;    // candidate list (bit patterns)
+  const float* list;    // the tensor's full list (written by the repair launch only)
+  double gamma;         // numpy's interpolation weight for the full list
+  uint64_t k0, k1;      // wanted ranks of the full list
+  uint32_t m, s_lo, s_hi;  // sample entries, the sample ranks of the bracket
+  uint32_t ccap;        // capacity of the candidate list
+  uint32_t n;           // entries of the full list
+  uint32_t out;         // index of the result (float64)
+  uint32_t slot;        // index of the ListFeedState
+  uint32_t pad;
+};
+int sel_list_bracket(const ListJob* jobs, int count, ListFeedState* state, hipStream_t st);
+int sel_list_cand(const ListJob* jobs, int count, ListFeedState* state, double* out, hipStream_t st);
+int sel_list_repair(const ListJob* jobs, int count, const ListFeedState* state, double* out, hipStream_t st);
+bool sel_list_ranks(int64_t n, int64_t m, double pct, int64_t* k0, int64_t* k1, double* gamma, int64_t* s_lo, int64_t* s_hi);
+
 // ---- device side: per-lane state of a feeding kernel --------------------------------------------------
 // LDS pointers keep their address space in the type: through a generic pointer the compiler merges the table
 // update with the global overflow update into ONE flat atomic, which is several times slower than ds_add.

@@ -242,19 +242,19 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
 // histogram per tracked rank, then interpolated as k_sel_scan does.
 #define SEL_SMALL_N 32768
 #define SEL_SMALL_BITS 11
+// the keys of ranks r0 and r1 among x[0 .. n): every thread of the 1024-thread workgroup calls this
 template <typename T>
-__global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+__device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r0, uint64_t r1, uint64_t* key0, uint64_t* key1) {
   constexpr int NB = 1 << SEL_SMALL_BITS;
   __shared__ uint32_t hist[2][NB];
   __shared__ uint32_t wtot[16];
   __shared__ uint64_t s_prefix[2], s_rank[2];
-  const T* x = static_cast<const T*>(b.x[blockIdx.x]);
-  const int64_t n = b.n[blockIdx.x];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();  // (a previous call's shared state has been read)
   if (threadIdx.x == 0) {
     s_prefix[0] = s_prefix[1] = 0;
-    s_rank[0] = rk.k0[blockIdx.x];
-    s_rank[1] = rk.k1[blockIdx.x];
+    s_rank[0] = r0;
+    s_rank[1] = r1;
   }
   int remaining = sizeof(T) == 4 ? 31 : 63;  // key bits still unresolved; float32 keys sit in the high word
   const int low = sizeof(T) == 4 ? 32 : 0;    // bits below the key
@@ -301,7 +301,52 @@ __global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelR
     }
     remaining -= width;
   }
-  if (threadIdx.x == 0) finish_store(fin, blockIdx.x, s_prefix[0], s_prefix[1], rk.gamma[blockIdx.x]);
+  *key0 = s_prefix[0];
+  *key1 = s_prefix[1];
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+  uint64_t key0, key1;
+  sel_small_core<T>(static_cast<const T*>(b.x[blockIdx.x]), b.n[blockIdx.x], rk.k0[blockIdx.x], rk.k1[blockIdx.x], &key0,
+                    &key1);
+  if (threadIdx.x == 0) finish_store(fin, blockIdx.x, key0, key1, rk.gamma[blockIdx.x]);
+}
+
+// ---- percentile of a list selected inside the statistics pass (see mq_sel.h) ----------------------------------------
+__global__ __launch_bounds__(1024) void k_list_bracket(const ListJob* jobs, ListFeedState* state) {
+  const ListJob j = jobs[blockIdx.x];
+  uint64_t key0, key1;
+  sel_small_core<float>(j.samples, (int64_t)j.m, j.s_lo, j.s_hi, &key0, &key1);
+  if (threadIdx.x == 0) {
+    state[j.slot].blo = (uint32_t)(key0 >> 32);
+    state[j.slot].bhi = (uint32_t)(key1 >> 32);
+  }
+}
+__global__ __launch_bounds__(1024) void k_list_cand(const ListJob* jobs, ListFeedState* state, double* out) {
+  const ListJob j = jobs[blockIdx.x];
+  const ListFeedState s = state[j.slot];
+  // both ranks inside the kept values, and every kept value in the list?
+  const bool ok = s.ovf == 0 && s.cand_n <= j.ccap && j.k0 >= s.below && j.k1 < (uint64_t)s.below + s.cand_n;
+  if (!ok) {
+    if (threadIdx.x == 0) state[j.slot].miss = 1;
+    return;
+  }
+  uint64_t key0, key1;
+  sel_small_core<float>(j.cand, (int64_t)s.cand_n, j.k0 - s.below, j.k1 - s.below, &key0, &key1);
+  if (threadIdx.x == 0) {
+    const FinishArgs fin = {MQ_F32_AS_F64, reinterpret_cast<char*>(out), nullptr};
+    finish_store(fin, (int)j.out, key0, key1, j.gamma);
+  }
+}
+__global__ __launch_bounds__(1024) void k_list_repair(const ListJob* jobs, const ListFeedState* state, double* out) {
+  const ListJob j = jobs[blockIdx.x];
+  if (state[j.slot].miss == 0) return;
+  uint64_t key0, key1;
+  sel_small_core<float>(j.list, (int64_t)j.n, j.k0, j.k1, &key0, &key1);
+  if (threadIdx.x == 0) {
+    const FinishArgs fin = {MQ_F32_AS_F64, reinterpret_cast<char*>(out), nullptr};
+    finish_store(fin, (int)j.out, key0, key1, j.gamma);
+  }
 }
 
 // ---- levels 1..3 -----------------------------------------------------------------------------------
@@ -1069,6 +1114,40 @@ extern "C" int mq_percentile(const void* x, int32_t dtype, int64_t n, double pct
   if (!x) return MQ_ERR_ARG;
   const void* xs[1] = {x};
   return mq_percentile_batch(xs, 1, dtype, n, pct, out, out_pair, workspace, workspace_bytes, hip_stream);
+}
+
+// ---- list percentile fed by the statistics pass (see mq_sel.h) -------------------------------------------------
+#define SEL_LIST_SIGMAS 12.0
+// The wanted ranks of a list of n entries and the sample ranks of its bracket for m sample entries; false: not
+// worth feeding (short lists, quantiles too near an end for the margin).
+bool sel_list_ranks(int64_t n, int64_t m, double pct, int64_t* k0, int64_t* k1, double* gamma, int64_t* s_lo, int64_t* s_hi) {
+  if (mq_percentile_index(MQ_F32_AS_F64, n, pct, k0, k1, gamma)) return false;
+  if (m < 1 || n < 1 || n >= (1ll << 32)) return false;
+  const double frac = (double)m / (double)n, p = ((double)*k0 + 0.5) / (double)n;
+  const double margin = SEL_LIST_SIGMAS * __builtin_sqrt((double)m * p * (1.0 - p)) + 8.0;
+  const double lo = __builtin_floor((double)*k0 * frac) - margin, hi = __builtin_ceil((double)*k1 * frac) + margin;
+  if (!(lo >= 0.0 && hi <= (double)(m - 1))) return false;
+  *s_lo = (int64_t)lo;
+  *s_hi = (int64_t)hi;
+  return true;
+}
+int sel_list_bracket(const ListJob* jobs, int count, ListFeedState* state, hipStream_t st) {
+  if (count < 1) return MQ_OK;
+  hipLaunchKernelGGL(k_list_bracket, dim3((unsigned)count), dim3(1024), 0, st, jobs, state);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+int sel_list_cand(const ListJob* jobs, int count, ListFeedState* state, double* out, hipStream_t st) {
+  if (count < 1) return MQ_OK;
+  hipLaunchKernelGGL(k_list_cand, dim3((unsigned)count), dim3(1024), 0, st, jobs, state, out);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+int sel_list_repair(const ListJob* jobs, int count, const ListFeedState* state, double* out, hipStream_t st) {
+  if (count < 1) return MQ_OK;
+  hipLaunchKernelGGL(k_list_repair, dim3((unsigned)count), dim3(1024), 0, st, jobs, state, out);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
 }
 
 // ---- selection fed by another kernel (see mq_sel.h) ------------------------------------------------------

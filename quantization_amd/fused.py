@@ -255,6 +255,20 @@ def bind_batch():
         L_.mq_sweep_numpy_finish_workspace_bytes.argtypes = [i64, i64]
         L_.mq_sweep_numpy_finish.restype = ctypes.c_int
         L_.mq_sweep_numpy_finish.argtypes = [vp, i32, i64, vp, i64, i64, vp, vp, vp, sz, vp]
+        psz = ctypes.POINTER(sz)
+        L_.mq_sweep_feed_sizes.restype = ctypes.c_int
+        L_.mq_sweep_feed_sizes.argtypes = [pi64, pi64, i32, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
+                                           ctypes.POINTER(i32), psz, psz]
+        L_.mq_sweep_feed_prepare.restype = ctypes.c_int
+        L_.mq_sweep_feed_prepare.argtypes = [ctypes.POINTER(_QuantItem), pi64, pi64, i32, i32, ctypes.POINTER(_lib.QuantCfg),
+                                             ctypes.c_double, vp, sz, vp, sz, vp, sz, pi64, pi64, pi64, ctypes.POINTER(i32),
+                                             ctypes.POINTER(i32)]
+        L_.mq_sweep_feed_sample.restype = ctypes.c_int
+        L_.mq_sweep_feed_sample.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp]
+        L_.mq_sweep_feed_run.restype = ctypes.c_int
+        L_.mq_sweep_feed_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, sz, vp]
+        L_.mq_sweep_feed_finish.restype = ctypes.c_int
+        L_.mq_sweep_feed_finish.argtypes = [vp, i32, vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp]
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

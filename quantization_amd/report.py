@@ -260,6 +260,12 @@ class SweepPlan:
     0).  lists(k) -> the float32 per-vector MSE lists of pass k, in the order of `weights`.  Records and lists live in
     buffers of the plan: the next run() overwrites them.
 
+    feed_lists (default): in per-group passes the list of a large tensor (a quarter of a million entries and more) is
+    NOT written -- a sampling launch gives the tensor a bracket around the wanted quantile, the pass counts the entries
+    under it and keeps those inside, and the percentile is selected among the kept ones (exact: the sample only decides
+    where to look; a bracket that misses makes the repair launch write the list after all).  lists(k) of such a tensor
+    then holds nothing: pass feed_lists=False when the lists themselves are wanted (plan.fed(k) tells which).
+
     Per pass ONE fused launch takes every layer whose segments have one length, whatever the shapes (mq_sweep_run:
     per-group passes the whole model, per-channel passes the layers of one column count; statistics only, float32
     MSE lists); layers the sweep form does not take go in batches of 32 same-shaped ones (mq_quantize_batch;
@@ -270,7 +276,8 @@ class SweepPlan:
     batched launches and the slower wave-per-segment kernel); mse_rep and mse_p99 of the records and the tensor means
     in `mse_tensor` [len(passes), len(weights)] then have the reference's bits."""
 
-    def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True):
+    def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True,
+                 feed_lists: bool = True):
         import ctypes
         import os
         from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
@@ -302,6 +309,8 @@ class SweepPlan:
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
             single_launch = False
+        if os.environ.get("MQ_SWEEP_FEED", "1") == "0":     # (measurements with every list written)
+            feed_lists = False
         for datatype, bits, group_size in self.passes:
             fmt, table = format_code(datatype)
             if table in TABLE_LISTS:
@@ -386,6 +395,35 @@ class SweepPlan:
                     items = make_items(poss)
                     host = torch.empty(L.mq_sweep_table_bytes(n), dtype=torch.uint8)
                     seg_len, blocks = ctypes.c_int64(0), ctypes.c_int64(0)
+                    # the lists of large tensors are not written: their percentile is selected inside the pass
+                    # (a sampling launch gives each a bracket, the pass counts below it and keeps what lies inside)
+                    nfed, fws_b, aux_b = ctypes.c_int32(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+                    if feed_lists and gs > 0 and not numpy_order:
+                        _lib.check(L.mq_sweep_feed_sizes(rows, cols, n, ctypes.byref(cfg), self.pct, ctypes.byref(nfed),
+                                                         ctypes.byref(fws_b), ctypes.byref(aux_b)))
+                    if nfed.value > 0:
+                        fws = torch.empty(fws_b.value, dtype=torch.uint8, device=dev)
+                        aux = torch.empty(aux_b.value, dtype=torch.uint8)
+                        sblocks = ctypes.c_int64(0)
+                        fed_rows = (ctypes.c_int32 * n)()
+                        rc = L.mq_sweep_feed_prepare(items, rows, cols, n, _DTYPES[dtype], ctypes.byref(cfg), self.pct,
+                                                     fws.data_ptr(), fws.numel(), host.data_ptr(), host.numel(),
+                                                     aux.data_ptr(), aux.numel(), ctypes.byref(seg_len),
+                                                     ctypes.byref(blocks), ctypes.byref(sblocks), ctypes.byref(nfed),
+                                                     fed_rows)
+                        if rc == _lib.OK:
+                            frows = [fed_rows[j] for j in range(nfed.value)]
+                            # (table, tensors, segment length, workgroups, dtype, aux, fed tensors, sampling workgroups,
+                            #  feed workspace, fed rows of the table, their positions in the pass, results by table row)
+                            launches.append(("feedsweep", host.to(dev), n, seg_len.value, blocks.value, _DTYPES[dtype],
+                                             aux.to(dev), nfed.value, sblocks.value, fws,
+                                             torch.tensor(frows, dtype=torch.int64, device=dev),
+                                             torch.tensor([poss[r] for r in frows], dtype=torch.int64, device=dev),
+                                             torch.zeros(n, dtype=torch.float64, device=dev)))
+                            self.ws_bytes = max(self.ws_bytes, L.mq_sweep_workspace_bytes(blocks.value))
+                            continue
+                        if rc != _lib.ERR_UNSUPPORTED:
+                            _lib.check(rc)
                     rc = L.mq_sweep_prepare(items, rows, cols, n, _DTYPES[dtype], ctypes.byref(cfg), host.data_ptr(),
                                             host.numel(), ctypes.byref(seg_len), ctypes.byref(blocks))
                     if rc == _lib.OK:
@@ -408,12 +446,30 @@ class SweepPlan:
             if numpy_order:
                 params = [(scl[offs[pos]:offs[pos] + ns[pos]],
                            None if zpt is None else zpt[offs[pos]:offs[pos] + ns[pos]]) for pos in range(nl)]
+            # which lists are written (and selected from as always): all but the fed tensors of a feeding launch
+            fed = torch.zeros(nl, dtype=torch.bool)
+            for la in launches:
+                if la[0] == "feedsweep":
+                    fed[la[11].cpu()] = True
+            written = [pos for pos in range(nl) if not bool(fed[pos])]
+            sel = dict(ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns), n=nl, idx=None, tmp=None)
+            if len(written) < nl:
+                sel = dict(ptrs=(ctypes.c_void_p * len(written))(*[ptrs[pos] for pos in written]),
+                           ns=(ctypes.c_int64 * len(written))(*[ns[pos] for pos in written]), n=len(written),
+                           idx=torch.tensor(written, dtype=torch.int64, device=dev),
+                           tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
             self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
-                                  ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns), slow_pos=slow_pos))
+                                  sel=sel, slow_pos=slow_pos, fed=fed))
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
 
     def lists(self, k: int):
         return self.plan[k]["lists"]
+
+    def fed(self, k: int) -> torch.Tensor:
+        """bool [len(weights)]: whose list of pass k is selected inside the pass instead of written."""
+        out = torch.zeros(len(self.weights), dtype=torch.bool)
+        out[torch.tensor(self.order)] = self.plan[k]["fed"]
+        return out
 
     @torch.no_grad()
     def run(self, overlap: bool = True) -> torch.Tensor:
@@ -446,12 +502,31 @@ class SweepPlan:
                     fin = _side_streams[(dev.index, "fin")] = torch.cuda.Stream(device=dev)
                 fin.wait_stream(main)
             ws, _ = workspace(dev, self.ws_bytes)
+            # the sampling launches of pass k (fed lists: samples -> brackets) go to the second stream ahead of the
+            # selections of pass k - 1, so that they run beside the launches of pass k - 1
+            def sample(k):
+                ev = None
+                for la in self.plan[k]["launches"]:
+                    if la[0] == "feedsweep":
+                        _lib.check(L.mq_sweep_feed_sample(la[6].data_ptr(), la[7], la[3], la[8], la[5],
+                                                          ctypes.byref(self.plan[k]["cfg"]), la[9].data_ptr(),
+                                                          side.cuda_stream))
+                        ev = ev or torch.cuda.Event()
+                if ev is not None:
+                    ev.record(side)
+                return ev
+            sampled = sample(0)
             for k, ps in enumerate(self.plan):
                 cfg = ps["cfg"]
+                if sampled is not None and side is not main:
+                    main.wait_event(sampled)
                 for la in ps["launches"]:
                     if la[0] == "npsweep":
                         _lib.check(L.mq_sweep_numpy_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
                                                         ws.data_ptr(), ws.numel(), main.cuda_stream))
+                    elif la[0] == "feedsweep":
+                        _lib.check(L.mq_sweep_feed_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
+                                                       ws.data_ptr(), ws.numel(), main.cuda_stream))
                     elif la[0] == "sweep":
                         _, tab, n, seg_len, blocks, dt, flag = la
                         _lib.check(L.mq_sweep_run(tab.data_ptr(), n, seg_len, blocks, dt, ctypes.byref(cfg), flag,
@@ -462,12 +537,24 @@ class SweepPlan:
                                                        main.cuda_stream))
                 ready = torch.cuda.Event()
                 ready.record(main)
+                sampled = sample(k + 1) if k + 1 < len(self.plan) else None
                 with torch.cuda.stream(side):
                     side.wait_event(ready)
                     sws, _ = workspace(dev, self.side_ws_bytes)
-                    _lib.check(L.mq_percentile_multi(ps["ptrs"], ps["ns"], nl, _lib.F32_AS_F64, self.pct,
-                                                     ps["p99"].data_ptr(), None, sws.data_ptr(), sws.numel(),
-                                                     side.cuda_stream))
+                    sel = ps["sel"]
+                    if sel["n"]:
+                        out = ps["p99"] if sel["idx"] is None else sel["tmp"]
+                        _lib.check(L.mq_percentile_multi(sel["ptrs"], sel["ns"], sel["n"], _lib.F32_AS_F64, self.pct,
+                                                         out.data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                         side.cuda_stream))
+                        if sel["idx"] is not None:
+                            ps["p99"].index_copy_(0, sel["idx"], out)
+                    for la in ps["launches"]:   # the fed lists: the wanted ranks among the kept entries
+                        if la[0] == "feedsweep":
+                            _lib.check(L.mq_sweep_feed_finish(la[1].data_ptr(), la[2], la[6].data_ptr(), la[7], la[3], la[4],
+                                                              la[5], ctypes.byref(cfg), la[9].data_ptr(), la[12].data_ptr(),
+                                                              side.cuda_stream))
+                            ps["p99"].index_copy_(0, la[11], la[12][la[10]])
                     # the pass's rows of the record table (one launch: mean = sse / numel, NaN lists, row order)
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
                                                   self.perm.data_ptr(), nl, self.records[k].data_ptr(),
@@ -555,7 +642,8 @@ def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = Non
     weights, passes = list(weights), list(passes)
     if numpy_order is None:
         numpy_order = numpy_order_available(weights, passes)
-    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order)
+    # (with vecs_of every list is written; otherwise the percentile of a large tensor's list is selected inside the pass)
+    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order, feed_lists=vecs_of is None)
     out = plan.run()
     res = [out]
     if vecs_of is not None:

@@ -466,3 +466,61 @@ def test_bench_two_ranks_end_to_end(tmp_path):
     assert t1["table"].shape == t2["table"].shape == (4 * 225, 6)
     assert np.array_equal(t1["table"].view(np.int64), t2["table"].view(np.int64))
     assert t1["p99"].tobytes() == t2["p99"].tobytes()
+
+
+def _feed_weights(dist="normal"):
+    g = torch.Generator(device="cuda").manual_seed(91)
+    ws = []
+    for s in [(2048, 4096), (4096, 4096), (1024, 4096), (4096, 14336), (512, 2048)]:
+        x = torch.randn(*s, generator=g, device="cuda")
+        if dist == "student_t":
+            chi = sum(torch.randn(*s, generator=g, device="cuda") ** 2 for _ in range(3))
+            x = x / torch.sqrt(chi / 3)
+        ws.append((x * 0.02).to(torch.bfloat16))
+    return ws
+
+
+@pytest.mark.parametrize("dist", ["normal", "student_t"])
+def test_list_percentile_selected_inside_the_pass(dist):
+    """Per-group passes over large tensors: the list is not written, its P99 comes from the entries the pass kept
+    inside the sampled bracket -- every record equals the one taken from the written list, bit for bit."""
+    from quantization_amd import report
+    ws = _feed_weights(dist)
+    ws[1][7, :64] = float("nan")                       # a tensor whose list holds a NaN: mse_p99 is NaN either way
+    passes = [("int8", 8, 32), ("int8_asym", 8, 64), ("fp8_e4m3", 8, 32), ("int8", 8, 128), ("int8", 8, None), ("fp4", 4, 64)]
+    fed = report.SweepPlan(ws, passes)
+    ref = report.SweepPlan(ws, passes, feed_lists=False)
+    assert bool(fed.fed(0)[:2].all()) and bool(fed.fed(0)[3]) and not bool(fed.fed(0)[2]) and not bool(fed.fed(0)[4])
+    assert not bool(fed.fed(4).any()) and not bool(ref.fed(0).any())       # rows are never fed
+    assert bool(fed.fed(1)[3])                                            # g = 64: the large tensors
+    for it in range(3):
+        a = fed.run(overlap=it != 1).clone()
+        b = ref.run(overlap=it != 1).clone()
+        torch.cuda.synchronize()
+        same = (a.view(torch.int64) == b.view(torch.int64)) | (a.isnan() & b.isnan())
+        assert bool(same.all()), (dist, it, same.logical_not().nonzero()[:6].tolist())
+
+
+def test_list_percentile_survives_a_misleading_sample():
+    """The sampling launch evaluates wave step c * unit + ((c * 0x9E3779B1 mod 2^32) >> 8) mod unit of every unit of
+    steps (2048 weights each at g = 32).  Zero weights in exactly those steps make every sample entry 0 and the bracket
+    [0, 0]: the wanted ranks are not inside, the repair launch writes the list after all and the result is the same."""
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(92)
+    rows, cols, gs = 4096, 4096, 32
+    w = (torch.randn(rows, cols, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    nsteps = rows * cols // 2048
+    unit = max(16, nsteps // 512)
+    c = np.arange(nsteps // unit, dtype=np.uint64)
+    step = c * np.uint64(unit) + (((c * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(8)) % np.uint64(unit)
+    w.view(-1, 2048)[torch.from_numpy(step.astype(np.int64)).cuda()] = 0
+    other = (torch.randn(2048, 4096, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    fed = report.SweepPlan([w, other], [("int8", 8, gs)])
+    ref = report.SweepPlan([w, other], [("int8", 8, gs)], feed_lists=False)
+    assert bool(fed.fed(0).all())
+    a, b = fed.run().clone(), ref.run().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert float(a[0, 0, 4]) > 0
+    # the repaired tensor's list was written after all
+    assert torch.equal(fed.lists(0)[0].view(torch.int32), ref.lists(0)[0].view(torch.int32))
