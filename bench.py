@@ -45,7 +45,7 @@ GROUPS = (None, 32, 64, 128)
 # Order of the passes in a model sweep: the selections of a pass run under the launches of the next one, only the
 # last pass's are exposed -- so the longest lists (g = 32) go first and the per-channel pass, whose lists are the
 # rows of a layer, goes last.
-SWEEP_ORDER = (32, 64, 128, None)
+SWEEP_ORDER = tuple((None if g == "pc" else int(g)) for g in os.environ.get("MQ_BENCH_ORDER", "32,64,128,pc").split(","))
 REFERENCE_BUILD_CONTAINER = {
     # the reference itself (imported quant_weight._int_quant_meta on torch CPU + the scripts' numpy arithmetic) on
     # the c2 unit of work, timed in the build container by scratch/ref_time.py; /root/reference does not exist
@@ -146,15 +146,20 @@ class ModelSweep:
         self.local_elems = sum(sizes[i] for i in self.mine)
         self.total_weight_bytes = sum(sizes) * esz * len(self.passes)          # whole job, every pass counts
         self.local_weight_bytes = self.local_elems * esz * len(self.passes)
-        stats = dict(seg_mse=True)
-        self.local_algo_bytes = sum(
-            sizes[i] * algorithmic_bytes_per_elem(esz, f.startswith("fp"), "asym" in f, gs, stats)
-            + (4 * self.layers[i][1][0] if gs is None else 0)                  # per-row MSEs of the per-channel passes
-            for i in self.mine for f, _, gs in self.passes)
+        # every pass of the sweep over this rank's resident layers: launch descriptors and buffers are prepared once
+        from quantization_amd.report import SweepPlan
+        self.plan = SweepPlan(self.weights, self.passes, numpy_order=bool(numpy_order)) if self.weights else None
+        # algorithmic bytes: every weight once per pass, plus the float32 per-vector list where the pass writes it (the
+        # list of a large tensor in a per-group pass is not written: its percentile is selected inside the pass)
+        self.local_algo_bytes = 0
+        for k, (f, _, gs) in enumerate(self.passes):
+            fed = self.plan.fed(k) if self.plan is not None else []
+            for j, i in enumerate(self.mine):
+                r, c = self.layers[i][1]
+                self.local_algo_bytes += sizes[i] * esz + (0 if bool(fed[j]) else 4 * (r if gs is None else sizes[i] // gs))
         self.launches_hint = sum(-(-sum(1 for i in self.mine if self.layers[i][1] == sh) // 32)
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
-        self.plan = None
         self.host_table = self.host_p99 = None
         self.numpy_order = bool(numpy_order)
         self.overlap = True   # selections of pass k on a second stream under the launches of pass k + 1
@@ -181,10 +186,7 @@ class ModelSweep:
         from quantization_amd.report import RECORD_FIELDS, SweepPlan
         local, vecs = None, []
         if self.weights:
-            # every pass of the sweep over this rank's resident layers (launch descriptors and buffers prepared once);
             # the per-channel lists of the first format feed the model-wide percentile
-            if self.plan is None:
-                self.plan = SweepPlan(self.weights, self.passes, numpy_order=self.numpy_order)
             self.plan.launch(overlap=self.overlap)
             vecs = self.plan.lists(self.joint_pass)
         # RCCL: the histogram all-reduces (one per radix level) of a P99 taken over every rank's lists -- enqueued
@@ -288,6 +290,14 @@ class Workload:
                                                                      f == _lib.INT_ASYM, gs, o)
                               + (4 * w.shape[0] * w.shape[1] if (gs is None and o.get("seg_mse")) else 0)
                               for w, f, _, gs, o in self.batches)
+        if self.sweep is not None:
+            # the model-sweep entry point over this GPU's resident tensors; its fed lists are not written (see ModelSweep)
+            from quantization_amd.report import SweepPlan
+            self.plan = SweepPlan(*self.sweep)
+            ws, ps = self.sweep
+            self.algo_bytes = sum(w.numel() * 2 + (0 if bool(self.plan.fed(k)[j]) else
+                                                   4 * (w.shape[0] if gs is None else w.numel() // gs))
+                                  for k, (_, _, gs) in enumerate(ps) for j, w in enumerate(ws))
         self.launches = len(self.batches)
         self.device = device
         self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
@@ -304,10 +314,7 @@ class Workload:
         from quantization_amd.error_metrics import percentile_rows
         from quantization_amd.fused import QuantResult, quantize_batch
         if self.sweep is not None:
-            # the model-sweep entry point over this GPU's resident tensors: records [passes, tensors, fields]
-            if self.plan is None:
-                from quantization_amd.report import SweepPlan
-                self.plan = SweepPlan(*self.sweep)
+            # records [passes, tensors, fields]
             return self.to_host(self.plan.run(overlap=self.overlap))
         results, row = [], 0
         for k, (w, fmt, dt, gs, outs) in enumerate(self.batches):

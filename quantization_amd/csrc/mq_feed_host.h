@@ -27,8 +27,23 @@ static bool feed_choice(int64_t nseg, int team_log2, double pct, FeedChoice* c) 
   return true;
 }
 static size_t feed_align(size_t v) { return (v + 255) / 256 * 256; }
+// workgroups mq_sweep_prepare gives a tensor of nseg groups (its formula for the group kernels)
+static int64_t feed_tensor_blocks(int64_t nseg, int team_log2) {
+  int64_t units_per_block = sweep_wg_bytes() / 4096 / 4;
+  if (units_per_block < 1) units_per_block = 1;
+  units_per_block *= 4;
+  const int64_t spw = 64 >> team_log2, units = (nseg + spw - 1) / spw;
+  const int64_t nb = (units + units_per_block - 1) / units_per_block;
+  return nb < 1 ? 1 : nb;
+}
+// 32-bit words of feed_ws one fed tensor takes: samples, packed kept entries, the waves' counts and slots
+static size_t feed_tensor_words(const FeedChoice& c, int64_t nblk) {
+  auto r = [](size_t v) { return (v + 63) / 64 * 64; };
+  return r((size_t)c.m) + r((size_t)c.ccap) + r((size_t)nblk * 4 * 2) + (size_t)nblk * 4 * LIST_SLOT;
+}
 
-// feed_ws (device, one per pass): [ListFeedState x nfed][samples][candidate lists]
+// feed_ws (device, one per pass): [ListFeedState x nfed], then per fed tensor its samples, room for the packed kept
+// entries, its workgroups' counts and slots
 extern "C" int mq_sweep_feed_sizes(const int64_t* rows, const int64_t* cols, int32_t count, const mq_quant_cfg* cfg,
                                    double pct, int32_t* nfed, size_t* feed_ws_bytes, size_t* aux_bytes) {
   if (!rows || !cols || count < 1 || !cfg || !nfed || !feed_ws_bytes || !aux_bytes) return MQ_ERR_ARG;
@@ -44,9 +59,10 @@ extern "C" int mq_sweep_feed_sizes(const int64_t* rows, const int64_t* cols, int
   for (int32_t i = 0; i < count; ++i) {
     if (rows[i] < 1 || cols[i] < 1) return MQ_ERR_ARG;
     FeedChoice c;
-    if (!feed_choice(rows[i] * cols[i] / cfg->group_size, team_log2, pct, &c)) continue;
+    const int64_t nseg = rows[i] * cols[i] / cfg->group_size;
+    if (!feed_choice(nseg, team_log2, pct, &c)) continue;
     ++n;
-    floats += (size_t)(c.m + 63) / 64 * 64 + ((size_t)c.ccap + 63) / 64 * 64;
+    floats += feed_tensor_words(c, feed_tensor_blocks(nseg, team_log2));
   }
   *nfed = n;
   if (n) {
@@ -62,10 +78,10 @@ extern "C" int mq_sweep_feed_sizes(const int64_t* rows, const int64_t* cols, int
 // of the fed tensors go to p99_out[row] (mq_sweep_feed_finish).
 extern "C" int mq_sweep_feed_prepare(const mq_quant_item* items, const int64_t* rows, const int64_t* cols, int32_t count,
                                      int32_t w_dtype, const mq_quant_cfg* cfg, double pct, void* feed_ws_dev,
-                                     size_t feed_ws_bytes, void* table_host, size_t table_bytes, void* aux_host,
+                                     size_t feed_ws_bytes, void* table_dev, void* table_host, size_t table_bytes, void* aux_host,
                                      size_t aux_bytes, int64_t* seg_len, int64_t* total_blocks, int64_t* sample_blocks,
                                      int32_t* nfed_out, int32_t* fed_rows) {
-  if (!sample_blocks || !nfed_out || !feed_ws_dev || !aux_host || !fed_rows) return MQ_ERR_ARG;
+  if (!sample_blocks || !nfed_out || !feed_ws_dev || !aux_host || !fed_rows || !table_dev) return MQ_ERR_ARG;
   int32_t nfed = 0;
   size_t need_ws = 0, need_aux = 0;
   if (int rc = mq_sweep_feed_sizes(rows, cols, count, cfg, pct, &nfed, &need_ws, &need_aux)) return rc;
@@ -86,17 +102,23 @@ extern "C" int mq_sweep_feed_prepare(const mq_quant_item* items, const int64_t* 
   for (int32_t i = 0; i < count; ++i) {
     FeedChoice c;
     if (!feed_choice(t[i].nseg, team_log2, pct, &c)) continue;
+    if ((int64_t)t[i].nblk != feed_tensor_blocks(t[i].nseg, team_log2)) return MQ_ERR_UNSUPPORTED;  // (sizes assumed it)
+    auto r64 = [](size_t v) { return (v + 63) / 64 * 64; };
     float* samples = pool;
-    pool += (size_t)(c.m + 63) / 64 * 64;
+    pool += r64((size_t)c.m);
     float* cand = pool;
-    pool += ((size_t)c.ccap + 63) / 64 * 64;
+    pool += r64((size_t)c.ccap);
+    uint32_t* wg_cnt = reinterpret_cast<uint32_t*>(pool);
+    pool += r64((size_t)t[i].nblk * 4 * 2);
+    uint32_t* slots = reinterpret_cast<uint32_t*>(pool);
+    pool += (size_t)t[i].nblk * 4 * LIST_SLOT;
     t[i].feed = state + f;
-    t[i].cand = cand;
-    t[i].ccap = c.ccap;
+    t[i].wg_cnt = wg_cnt;
+    t[i].slots = slots;
     // the sampling launch: a workgroup per 16 sampled steps (four per wave)
     const int64_t nb = ((int64_t)c.scount + 15) / 16;
-    st[f] = t[i];
-    st[f].scale = nullptr; st[f].zp = nullptr; st[f].seg_sse = nullptr; st[f].totals = nullptr;
+    st[f] = t[i];  // (the repair launch walks this table too: it keeps the list pointer)
+    st[f].scale = nullptr; st[f].zp = nullptr; st[f].totals = nullptr;
     st[f].blk0 = (uint32_t)sblocks;
     st[f].nblk = (uint32_t)nb;
     st[f].sample = samples;
@@ -107,6 +129,10 @@ extern "C" int mq_sweep_feed_prepare(const mq_quant_item* items, const int64_t* 
     j.samples = samples;
     j.cand = cand;
     j.list = reinterpret_cast<const float*>(t[i].seg_sse);
+    j.wg_cnt = wg_cnt;
+    j.slots = slots;
+    j.brk = &static_cast<SweepItem*>(table_dev)[i].blo;
+    j.nblk = t[i].nblk * 4u;
     j.gamma = c.gamma;
     j.k0 = (uint64_t)c.k0;
     j.k1 = (uint64_t)c.k1;
@@ -173,7 +199,7 @@ extern "C" int mq_sweep_feed_sample(const void* aux_dev, int32_t nfed, int64_t s
   feed_launch(cfg->format, scope, nv, team_log2, dim3((unsigned)sample_blocks), st, b);
   MQ_HIP(hipGetLastError());
   const ListJob* jobs = reinterpret_cast<const ListJob*>(static_cast<const char*>(aux_dev) + feed_align((size_t)nfed * sizeof(SweepItem)));
-  return sel_list_bracket(jobs, nfed, static_cast<ListFeedState*>(feed_ws_dev), st);
+  return sel_list_bracket(jobs, nfed, st);
 }
 
 // The pass: mq_sweep_run with the fed tensors' lists counted and kept instead of written.
@@ -206,11 +232,10 @@ extern "C" int mq_sweep_feed_run(const void* table_dev, int32_t count, int64_t s
 
 // After the pass: the wanted ranks among the kept entries -> p99_out[tensor]; for a tensor whose bracket missed the
 // repair launches (they return at once otherwise) write its list after all and select from it.
-extern "C" int mq_sweep_feed_finish(const void* table_dev, int32_t count, const void* aux_dev, int32_t nfed, int64_t seg_len,
-                                    int64_t total_blocks, int32_t w_dtype, const mq_quant_cfg* cfg, void* feed_ws_dev,
-                                    double* p99_out, void* hip_stream) {
-  if (!table_dev || !aux_dev || count < 1 || nfed < 1 || !feed_ws_dev || !p99_out || total_blocks < 1 ||
-      total_blocks > 0x7fffffffll)
+extern "C" int mq_sweep_feed_finish(const void* aux_dev, int32_t nfed, int64_t seg_len, int64_t sample_blocks,
+                                    int32_t w_dtype, const mq_quant_cfg* cfg, void* feed_ws_dev, double* p99_out,
+                                    void* hip_stream) {
+  if (!aux_dev || nfed < 1 || !feed_ws_dev || !p99_out || sample_blocks < 1 || sample_blocks > 0x7fffffffll)
     return MQ_ERR_ARG;
   if (!aligned(p99_out, 8)) return MQ_ERR_ALIGN;
   QuantBatch b = {};
@@ -220,11 +245,13 @@ extern "C" int mq_sweep_feed_finish(const void* table_dev, int32_t count, const 
   const ListJob* jobs = reinterpret_cast<const ListJob*>(static_cast<const char*>(aux_dev) + feed_align((size_t)nfed * sizeof(SweepItem)));
   ListFeedState* state = static_cast<ListFeedState*>(feed_ws_dev);
   if (int rc = sel_list_cand(jobs, nfed, state, p99_out, st)) return rc;
+  // the repair launch walks the fed tensors with the sampling launch's (small) grid: nearly always it has nothing
+  // to do, and then it costs a few microseconds
   b.common.list_mode = LIST_REPAIR;
-  b.sweep = static_cast<const SweepItem*>(table_dev);
-  b.sweep_count = count;
-  b.sweep_partials = nullptr;  // (the repair launch writes no partial sums)
-  feed_launch(cfg->format, scope, nv, team_log2, dim3((unsigned)total_blocks), st, b);
+  b.sweep = static_cast<const SweepItem*>(aux_dev);
+  b.sweep_count = nfed;
+  b.sweep_partials = nullptr;  // (it writes no partial sums)
+  feed_launch(cfg->format, scope, nv, team_log2, dim3((unsigned)sample_blocks), st, b);
   MQ_HIP(hipGetLastError());
   return sel_list_repair(jobs, nfed, state, p99_out, st);
 }

@@ -319,8 +319,8 @@ extern "C" int mq_sweep_numpy_prepare(const mq_quant_item* items, const int64_t*
     if (nb < 1) nb = 1;
     if (blocks + nb > 0x7fffffffll || lchunks + nseg / 8192 > 0x7fffffffll) return MQ_ERR_TOO_LARGE;
     t[i] = SweepItem{items[i].w, static_cast<uint16_t*>(o.scale), static_cast<uint16_t*>(o.zero_point), o.seg_sse,
-                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, leaf_sums + leaves, (uint32_t)lchunks, 0u, nullptr, nullptr,
-                     nullptr, 0u, 0u};
+                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, leaf_sums + leaves, (uint32_t)lchunks, 0u, nullptr, 0u, 0u,
+                     nullptr, nullptr, nullptr, 0u, 0u};
     if (!list_prog(nseg % 8192, &tails[i])) return MQ_ERR_UNSUPPORTED;
     blocks += nb;
     leaves += n / 128;

@@ -44,7 +44,6 @@ enum { SC_SUBWAVE = 0, SC_WAVE = 1, SC_BLOCK = 2, SC_TENSOR = 3,
 // drops the per-vector tests of the output pointers and everything that only served the stores.
 enum { SEL_STATS_ONLY = 3 };
 enum { LIST_OFF = 0, LIST_SAMPLE = 1, LIST_FEED = 2, LIST_REPAIR = 3 };
-#define LIST_STAGE_CAP 4096  // in-bracket entries a workgroup can stage (it sees at most ~2100 entries at 128 KiB)
 #define SEL_FEEDS(S) ((S) == SEL_FEED_SAMPLE || (S) == SEL_FEED_COUNT)
 #define SEL_STORES(S) ((S) == SEL_FEED_OFF || (S) == SEL_FEED_COUNT)  // may have element-sized outputs
 
@@ -87,8 +86,9 @@ struct QuantParams {
   // sweeps that select a list's percentile inside the pass (see mq_sel.h, ListFeedState):
   int32_t list_mode;     // LIST_OFF / LIST_SAMPLE (the sampling launch) / LIST_FEED (the pass) / LIST_REPAIR
   ListFeedState* feed;   // this tensor's feed state, or null: its list is written as always
-  float* cand;           // ... its candidate list
-  uint32_t ccap;
+  uint32_t blo, bhi;     // ... its bracket (float32 bit patterns, inclusive)
+  uint32_t* wg_cnt;      // ... per workgroup of the tensor: entries under the bracket, entries kept
+  uint32_t* slots;       // ... per workgroup: LIST_SLOT words for the kept bit patterns
   float* sample;         // sampling launch: where this tensor's sample entries go (null: not sampled)
   uint32_t sunit, scount;  // one wave step of every sunit is sampled, scount of them
   uint32_t bx, gx;       // this workgroup's index among the gx workgroups that share the tensor (blockIdx.x and
@@ -124,7 +124,7 @@ struct BatchItem {
 // One pass over tensors of DIFFERENT sizes in one launch (statistics kernels): a one-dimensional grid, tensor i
 // owns the workgroups [blk0, blk0 + nblk) and has its own segment count; the table lives in device memory (any
 // number of tensors; the kernel arguments could not hold it).
-struct SweepItem {  // 104 bytes
+struct SweepItem {  // 120 bytes
   const void* w;
   uint16_t* scale;
   uint16_t* zp;
@@ -134,13 +134,16 @@ struct SweepItem {  // 104 bytes
   uint32_t blk0, nblk;
   float* leaf;       // numpy-order sweeps: this tensor's 128-element leaf sums (flattened tensor)
   uint32_t lchunk0;  // ... and the index of its first whole 8192-entry chunk among those of all the pass's lists
-  uint32_t ccap;     // fed lists: capacity of the candidate list
-  ListFeedState* feed;  // fed lists: this tensor's state (null: the list is written), its candidate list, its samples
-  float* cand;
-  float* sample;
+  uint32_t pad;
+  ListFeedState* feed;  // fed lists: this tensor's state (null: the list is written)
+  uint32_t blo, bhi;    // ... its bracket, written into the DEVICE copy of the table by k_list_bracket
+  uint32_t* wg_cnt;     // ... the workgroups' counts and slots
+  uint32_t* slots;
+  float* sample;        // sampling launch: the sample entries
   uint32_t sunit, scount;
 };
-static_assert(sizeof(SweepItem) == 104, "table entry");
+static_assert(sizeof(SweepItem) == 120, "table entry");
+static_assert(offsetof(SweepItem, bhi) == offsetof(SweepItem, blo) + 4, "the bracket is stored as two words");
 // numpy's summation of a contiguous run of n float32 values (n a multiple of 8, n <= 32768), unrolled by the host:
 // chunks of 8192 elements (the reduction's inner loop size) added up in order, each chunk summed pairwise -- runs
 // longer than 128 elements are split in two, the left part n / 2 rounded down to a multiple of 8, until the parts
@@ -187,7 +190,8 @@ __device__ __forceinline__ QuantParams batch_params(const QuantBatch& b) {
     p.gx = it.nblk;
     p.partials = b.sweep_partials + 2 * (int64_t)it.blk0;
     p.leaf = it.leaf;
-    p.feed = it.feed; p.cand = it.cand; p.ccap = it.ccap; p.sample = it.sample; p.sunit = it.sunit; p.scount = it.scount;
+    p.feed = it.feed; p.blo = it.blo; p.bhi = it.bhi; p.wg_cnt = it.wg_cnt; p.slots = it.slots;
+    p.sample = it.sample; p.sunit = it.sunit; p.scount = it.scount;
     p.tred = nullptr; p.sel_ws = nullptr; p.sel_samples = nullptr;
     return p;
   }
@@ -1447,14 +1451,10 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
   if (list_mode == LIST_REPAIR && !(p.feed && p.feed->miss)) return;
   const bool sampling = list_mode == LIST_SAMPLE;
   const bool feeding = list_mode == LIST_FEED && p.feed != nullptr;
-  const uint32_t blo = feeding ? p.feed->blo : 0u, bhi = feeding ? p.feed->bhi : 0u;
-  __shared__ uint32_t stage_n, stage_below;
-  __shared__ uint32_t stage[EXACT ? 1 : LIST_STAGE_CAP];
-  uint32_t nbelow = 0;
-  if (feeding) {
-    if (threadIdx.x == 0) { stage_n = 0; stage_below = 0; }
-    __syncthreads();
-  }
+  const uint32_t blo = p.blo, bhi = p.bhi;
+  // every WAVE keeps its own slot and counts (wave-uniform registers: no shared counter, nothing to wait for)
+  uint32_t* const slot = feeding ? p.slots + ((size_t)p.bx * 4 + wv) * LIST_SLOT : nullptr;
+  uint32_t nbelow = 0, nkept = 0;
   const int64_t full = sampling ? (int64_t)p.scount : p.nseg / SPW;
   const int64_t steps = sampling ? (int64_t)p.scount : (p.nseg + SPW - 1) / SPW;
   // the wave step behind loop index t: itself, or -- sampling -- the chosen step of unit t
@@ -1529,11 +1529,9 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
       const bool inb = mine && bits >= blo && bits <= bhi;        // (a NaN entry lies above every bracket)
       const unsigned long long mask = __builtin_amdgcn_ballot_w64(inb);
       if (mask) {
-        const int leader = __builtin_ctzll(mask);
-        uint32_t at = 0u;
-        if (lane == leader) at = atomicAdd(&stage_n, (uint32_t)__builtin_popcountll(mask));
-        at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader) + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        if (inb && at < (uint32_t)LIST_STAGE_CAP) stage[at] = bits;
+        const uint32_t at = nkept + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (inb && at < (uint32_t)LIST_SLOT) slot[at] = bits;
+        nkept += (uint32_t)__builtin_popcountll(mask);
       }
     } else if (p.seg_sse) {
       s = team_sum<T>(s);
@@ -1605,22 +1603,13 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     }
   }
   if constexpr (!EXACT) {
-    if (feeding) {  // the workgroup's count and kept entries -> the tensor's
+    if (feeding) {  // the wave's counts (plain stores: k_list_cand adds them up)
       for (int off = 32; off > 0; off >>= 1) nbelow += __shfl_xor(nbelow, off);
-      if (lane == 0 && nbelow) atomicAdd(&stage_below, nbelow);
-      __syncthreads();
-      __shared__ uint32_t gbase;
-      const uint32_t cnt = stage_n;
-      if (threadIdx.x == 0) {
-        if (stage_below) atomicAdd(&p.feed->below, stage_below);
-        gbase = cnt ? atomicAdd(&p.feed->cand_n, cnt) : 0u;
-        if (cnt > (uint32_t)LIST_STAGE_CAP) p.feed->ovf = 1u;
+      if (lane == 0) {
+        p.wg_cnt[2 * ((size_t)p.bx * 4 + wv)] = nbelow;
+        p.wg_cnt[2 * ((size_t)p.bx * 4 + wv) + 1] = nkept;
+        if (nkept > (uint32_t)LIST_SLOT) p.feed->ovf = 1u;
       }
-      __syncthreads();
-      const uint32_t g0 = gbase, m = cnt < (uint32_t)LIST_STAGE_CAP ? cnt : (uint32_t)LIST_STAGE_CAP;
-      uint32_t* cand = reinterpret_cast<uint32_t*>(p.cand);
-      for (uint32_t i = threadIdx.x; i < m; i += 256)
-        if (g0 + i < p.ccap) cand[g0 + i] = stage[i];
     }
     // (the sampling and repair launches run beside another pass: its partial sums are not theirs to write)
     if (list_mode == LIST_SAMPLE || list_mode == LIST_REPAIR) return;
@@ -3087,7 +3076,8 @@ extern "C" int mq_sweep_prepare(const mq_quant_item* items, const int64_t* rows,
     if (nb < 1) nb = 1;
     if (blocks + nb > 0x7fffffffll) return MQ_ERR_TOO_LARGE;
     t[i] = SweepItem{items[i].w, static_cast<uint16_t*>(o.scale), static_cast<uint16_t*>(o.zero_point), o.seg_sse,
-                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, nullptr, 0u, 0u, nullptr, nullptr, nullptr, 0u, 0u};
+                     o.totals, nseg, (uint32_t)blocks, (uint32_t)nb, nullptr, 0u, 0u, nullptr, 0u, 0u, nullptr, nullptr, nullptr,
+                     0u, 0u};
     blocks += nb;
   }
   *seg_len = L;

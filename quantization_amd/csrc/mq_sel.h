@@ -87,28 +87,32 @@ int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, doubl
 // The counts are exact: the sample only decides where to look.  A bracket that does not hold both ranks (or a
 // candidate list that overflowed) sets `miss`; the repair launches then write that tensor's list after all and
 // select from it.
+#define LIST_SLOT 64    // kept entries a wave of the pass has room for (it sees ~500 entries, ~2 % are kept)
 struct ListFeedState {  // one per fed tensor, device memory; cleared before the sampling launch
-  uint32_t blo, bhi;    // written by k_list_bracket
-  uint32_t below;       // entries under the bracket          (statistics pass)
-  uint32_t cand_n;      // entries inside it, may pass ccap   (statistics pass)
-  uint32_t ovf;         // a workgroup's stage overflowed     (statistics pass)
-  uint32_t miss;        // written by k_list_cand
-  uint32_t pad[2];
+  uint32_t ovf;         // a wave of the pass kept more than LIST_SLOT entries
+  uint32_t miss;        // written by k_list_cand: the kept entries do not hold both ranks
 };
+// The pass writes no shared counter: wave w of a tensor (four per workgroup) puts the bit patterns it keeps into
+// its own slot (slots[w * LIST_SLOT ..]) and its two counts into wg_cnt[2 w] (entries under the bracket) and
+// wg_cnt[2 w + 1] (entries kept) -- wave-uniform registers and plain stores, nothing to wait for under a saturated
+// memory system.  k_list_cand adds the counts, packs the slots into one list and selects.
 struct ListJob {        // one per fed tensor, device memory, written by the host when the sweep is planned
   const float* samples; // sample entries
-  const float* cand;    // candidate list (bit patterns)
+  float* cand;          // room for the packed kept entries (ccap)
   const float* list;    // the tensor's full list (written by the repair launch only)
+  const uint32_t* wg_cnt;  // [nblk][2]   (nblk: WAVES of the tensor in the pass)
+  const uint32_t* slots;   // [nblk][LIST_SLOT]
+  uint32_t* brk;        // where the bracket goes: the blo / bhi fields of the tensor's entry in the pass's table
   double gamma;         // numpy's interpolation weight for the full list
   uint64_t k0, k1;      // wanted ranks of the full list
   uint32_t m, s_lo, s_hi;  // sample entries, the sample ranks of the bracket
-  uint32_t ccap;        // capacity of the candidate list
+  uint32_t ccap;        // capacity of cand
   uint32_t n;           // entries of the full list
+  uint32_t nblk;        // waves of the tensor in the pass (four per workgroup)
   uint32_t out;         // index of the result (float64)
   uint32_t slot;        // index of the ListFeedState
-  uint32_t pad;
 };
-int sel_list_bracket(const ListJob* jobs, int count, ListFeedState* state, hipStream_t st);
+int sel_list_bracket(const ListJob* jobs, int count, hipStream_t st);
 int sel_list_cand(const ListJob* jobs, int count, ListFeedState* state, double* out, hipStream_t st);
 int sel_list_repair(const ListJob* jobs, int count, const ListFeedState* state, double* out, hipStream_t st);
 bool sel_list_ranks(int64_t n, int64_t m, double pct, int64_t* k0, int64_t* k1, double* gamma, int64_t* s_lo, int64_t* s_hi);

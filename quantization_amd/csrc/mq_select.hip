@@ -242,10 +242,12 @@ __global__ __launch_bounds__(256) void k_sel_scan(const SelBatch b, int level, c
 // histogram per tracked rank, then interpolated as k_sel_scan does.
 #define SEL_SMALL_N 32768
 #define SEL_SMALL_BITS 11
-// the keys of ranks r0 and r1 among x[0 .. n): every thread of the 1024-thread workgroup calls this
-template <typename T>
+// the keys of ranks r0 and r1 among x[0 .. n): every thread of the workgroup (THREADS threads, a power of two
+// between 64 and 1024) calls this
+template <typename T, int THREADS = 1024>
 __device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r0, uint64_t r1, uint64_t* key0, uint64_t* key1) {
-  constexpr int NB = 1 << SEL_SMALL_BITS;
+  constexpr int NB = 1 << SEL_SMALL_BITS, BPT = NB / THREADS;  // bins, bins per thread
+  static_assert(BPT >= 2 && BPT * THREADS == NB, "every thread owns a whole run of bins");
   __shared__ uint32_t hist[2][NB];
   __shared__ uint32_t wtot[16];
   __shared__ uint64_t s_prefix[2], s_rank[2];
@@ -261,25 +263,27 @@ __device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r
   while (remaining > 0) {
     const int width = remaining < SEL_SMALL_BITS ? remaining : SEL_SMALL_BITS;
     const int shift = low + remaining - width;
-    for (int i = threadIdx.x; i < 2 * NB; i += blockDim.x) (&hist[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 2 * NB; i += THREADS) (&hist[0][0])[i] = 0;
     __syncthreads();
     const uint64_t p0 = s_prefix[0], p1 = s_prefix[1];
     const bool same = p0 == p1;
     const uint64_t himask = remaining == (sizeof(T) == 4 ? 31 : 63) ? 0ull : ~((1ull << (shift + width)) - 1ull);
     const uint32_t dmask = (1u << width) - 1u;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int64_t i = threadIdx.x; i < n; i += THREADS) {
       const uint64_t key = key_of(x[i]);
       const uint32_t d = (uint32_t)(key >> shift) & dmask;
       if ((key & himask) == p0) atomicAdd(&hist[0][d], 1u);
       if (!same && (key & himask) == p1) atomicAdd(&hist[1][d], 1u);
     }
     __syncthreads();
-    // locate each rank: every thread owns two consecutive bins
+    // locate each rank: every thread owns BPT consecutive bins
     for (int r = 0; r < 2; ++r) {
       const uint32_t* h = hist[(same || r == 0) ? 0 : 1];
       const uint64_t want = s_rank[r];
-      const uint32_t c0 = h[2 * threadIdx.x], c1 = h[2 * threadIdx.x + 1];
-      uint32_t inc = c0 + c1;
+      uint32_t c[BPT], mine = 0;
+#pragma unroll
+      for (int j = 0; j < BPT; ++j) { c[j] = h[BPT * threadIdx.x + j]; mine += c[j]; }
+      uint32_t inc = mine;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
         uint32_t o = __shfl_up(inc, off);
@@ -288,14 +292,18 @@ __device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r
       __syncthreads();  // (s_rank / wtot of the previous round have been read)
       if (lane == 63) wtot[wv] = inc;
       __syncthreads();
-      uint64_t before = inc - (c0 + c1);
+      uint64_t before = inc - mine;
       for (int w = 0; w < wv; ++w) before += wtot[w];
-      if (want >= before && want < before + c0) {
-        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint64_t)(2 * threadIdx.x) << shift);
-        s_rank[r] = want - before;
-      } else if (want >= before + c0 && want < before + c0 + c1) {
-        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint64_t)(2 * threadIdx.x + 1) << shift);
-        s_rank[r] = want - before - c0;
+      if (want >= before && want < before + mine) {
+        uint64_t at = before;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+          if (want >= at && want < at + c[j]) {
+            s_prefix[r] = (r == 0 ? p0 : p1) | ((uint64_t)(BPT * threadIdx.x + j) << shift);
+            s_rank[r] = want - at;
+          }
+          at += c[j];
+        }
       }
       __syncthreads();
     }
@@ -313,36 +321,84 @@ __global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelR
 }
 
 // ---- percentile of a list selected inside the statistics pass (see mq_sel.h) ----------------------------------------
-__global__ __launch_bounds__(1024) void k_list_bracket(const ListJob* jobs, ListFeedState* state) {
+// (The list kernels run beside the statistics pass of another group size: 256-thread workgroups find room on a busy
+//  chip where 1024-thread ones wait for a whole compute unit to drain.)
+#define LIST_THREADS 256
+__global__ __launch_bounds__(LIST_THREADS) void k_list_bracket(const ListJob* jobs) {
   const ListJob j = jobs[blockIdx.x];
   uint64_t key0, key1;
-  sel_small_core<float>(j.samples, (int64_t)j.m, j.s_lo, j.s_hi, &key0, &key1);
+  sel_small_core<float, LIST_THREADS>(j.samples, (int64_t)j.m, j.s_lo, j.s_hi, &key0, &key1);
   if (threadIdx.x == 0) {
-    state[j.slot].blo = (uint32_t)(key0 >> 32);
-    state[j.slot].bhi = (uint32_t)(key1 >> 32);
+    j.brk[0] = (uint32_t)(key0 >> 32);
+    j.brk[1] = (uint32_t)(key1 >> 32);
   }
 }
-__global__ __launch_bounds__(1024) void k_list_cand(const ListJob* jobs, ListFeedState* state, double* out) {
+__global__ __launch_bounds__(LIST_THREADS) void k_list_cand(const ListJob* jobs, ListFeedState* state, double* out) {
   const ListJob j = jobs[blockIdx.x];
-  const ListFeedState s = state[j.slot];
-  // both ranks inside the kept values, and every kept value in the list?
-  const bool ok = s.ovf == 0 && s.cand_n <= j.ccap && j.k0 >= s.below && j.k1 < (uint64_t)s.below + s.cand_n;
+  __shared__ uint32_t wsum[16][3];
+  __shared__ uint32_t s_below, s_total, s_over, s_carry;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // the workgroups' counts
+  uint32_t below = 0, total = 0, over = 0;
+  for (uint32_t w = threadIdx.x; w < j.nblk; w += LIST_THREADS) {
+    const uint32_t c = j.wg_cnt[2 * w + 1];
+    below += j.wg_cnt[2 * w];
+    total += c < (uint32_t)LIST_SLOT ? c : (uint32_t)LIST_SLOT;
+    over |= c > (uint32_t)LIST_SLOT ? 1u : 0u;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    below += __shfl_xor(below, off); total += __shfl_xor(total, off); over |= __shfl_xor(over, off);
+  }
+  if (lane == 0) { wsum[wv][0] = below; wsum[wv][1] = total; wsum[wv][2] = over; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, c = 0, o = 0;
+    for (int i = 0; i < LIST_THREADS / 64; ++i) { a += wsum[i][0]; c += wsum[i][1]; o |= wsum[i][2]; }
+    s_below = a; s_total = c; s_over = o | state[j.slot].ovf;
+    s_carry = 0;
+  }
+  __syncthreads();
+  below = s_below;
+  total = s_total;
+  // both ranks inside the kept values, and every kept value at hand?
+  const bool ok = s_over == 0 && total <= j.ccap && j.k0 >= below && j.k1 < (uint64_t)below + total;
   if (!ok) {
     if (threadIdx.x == 0) state[j.slot].miss = 1;
     return;
   }
+  // the slots packed into one list: a scan over the workgroups' counts, LIST_THREADS at a time
+  uint32_t* cand = reinterpret_cast<uint32_t*>(j.cand);
+  for (uint32_t w0 = 0; w0 < j.nblk; w0 += LIST_THREADS) {
+    const uint32_t w = w0 + threadIdx.x;
+    const uint32_t c = w < j.nblk ? j.wg_cnt[2 * w + 1] : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    __syncthreads();  // (the previous round's wsum / s_carry have been read)
+    if (lane == 63) wsum[wv][0] = inc;
+    __syncthreads();
+    uint32_t before = s_carry + inc - c;
+    for (int i = 0; i < wv; ++i) before += wsum[i][0];
+    for (uint32_t i = 0; i < c; ++i) cand[before + i] = j.slots[(size_t)w * LIST_SLOT + i];
+    __syncthreads();
+    if (threadIdx.x == LIST_THREADS - 1) s_carry = before + c;
+  }
+  __syncthreads();
   uint64_t key0, key1;
-  sel_small_core<float>(j.cand, (int64_t)s.cand_n, j.k0 - s.below, j.k1 - s.below, &key0, &key1);
+  sel_small_core<float, LIST_THREADS>(j.cand, (int64_t)total, j.k0 - below, j.k1 - below, &key0, &key1);
   if (threadIdx.x == 0) {
     const FinishArgs fin = {MQ_F32_AS_F64, reinterpret_cast<char*>(out), nullptr};
     finish_store(fin, (int)j.out, key0, key1, j.gamma);
   }
 }
-__global__ __launch_bounds__(1024) void k_list_repair(const ListJob* jobs, const ListFeedState* state, double* out) {
+__global__ __launch_bounds__(LIST_THREADS) void k_list_repair(const ListJob* jobs, const ListFeedState* state, double* out) {
   const ListJob j = jobs[blockIdx.x];
   if (state[j.slot].miss == 0) return;
   uint64_t key0, key1;
-  sel_small_core<float>(j.list, (int64_t)j.n, j.k0, j.k1, &key0, &key1);
+  sel_small_core<float, LIST_THREADS>(j.list, (int64_t)j.n, j.k0, j.k1, &key0, &key1);
   if (threadIdx.x == 0) {
     const FinishArgs fin = {MQ_F32_AS_F64, reinterpret_cast<char*>(out), nullptr};
     finish_store(fin, (int)j.out, key0, key1, j.gamma);
@@ -1131,21 +1187,21 @@ bool sel_list_ranks(int64_t n, int64_t m, double pct, int64_t* k0, int64_t* k1, 
   *s_hi = (int64_t)hi;
   return true;
 }
-int sel_list_bracket(const ListJob* jobs, int count, ListFeedState* state, hipStream_t st) {
+int sel_list_bracket(const ListJob* jobs, int count, hipStream_t st) {
   if (count < 1) return MQ_OK;
-  hipLaunchKernelGGL(k_list_bracket, dim3((unsigned)count), dim3(1024), 0, st, jobs, state);
+  hipLaunchKernelGGL(k_list_bracket, dim3((unsigned)count), dim3(LIST_THREADS), 0, st, jobs);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 int sel_list_cand(const ListJob* jobs, int count, ListFeedState* state, double* out, hipStream_t st) {
   if (count < 1) return MQ_OK;
-  hipLaunchKernelGGL(k_list_cand, dim3((unsigned)count), dim3(1024), 0, st, jobs, state, out);
+  hipLaunchKernelGGL(k_list_cand, dim3((unsigned)count), dim3(LIST_THREADS), 0, st, jobs, state, out);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 int sel_list_repair(const ListJob* jobs, int count, const ListFeedState* state, double* out, hipStream_t st) {
   if (count < 1) return MQ_OK;
-  hipLaunchKernelGGL(k_list_repair, dim3((unsigned)count), dim3(1024), 0, st, jobs, state, out);
+  hipLaunchKernelGGL(k_list_repair, dim3((unsigned)count), dim3(LIST_THREADS), 0, st, jobs, state, out);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }

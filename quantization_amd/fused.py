@@ -261,14 +261,14 @@ def bind_batch():
                                            ctypes.POINTER(i32), psz, psz]
         L_.mq_sweep_feed_prepare.restype = ctypes.c_int
         L_.mq_sweep_feed_prepare.argtypes = [ctypes.POINTER(_QuantItem), pi64, pi64, i32, i32, ctypes.POINTER(_lib.QuantCfg),
-                                             ctypes.c_double, vp, sz, vp, sz, vp, sz, pi64, pi64, pi64, ctypes.POINTER(i32),
+                                             ctypes.c_double, vp, sz, vp, vp, sz, vp, sz, pi64, pi64, pi64, ctypes.POINTER(i32),
                                              ctypes.POINTER(i32)]
         L_.mq_sweep_feed_sample.restype = ctypes.c_int
         L_.mq_sweep_feed_sample.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp]
         L_.mq_sweep_feed_run.restype = ctypes.c_int
         L_.mq_sweep_feed_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, sz, vp]
         L_.mq_sweep_feed_finish.restype = ctypes.c_int
-        L_.mq_sweep_feed_finish.argtypes = [vp, i32, vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp]
+        L_.mq_sweep_feed_finish.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp]
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

@@ -346,6 +346,8 @@ class SweepPlan:
                     o.abs_err_dtype = _lib.F32
                     o.seg_mse_f32 = 2 if numpy_order else 1   # (2: entries in numpy's summation order)
                     o.seg_sse = ptrs[pos]
+                    if os.environ.get("MQ_SWEEP_NOLIST") == "1":   # (measurements: the pass without its lists)
+                        o.seg_sse = None
                     o.totals = totals.data_ptr() + pos * 16
                     if scl is not None and params:
                         o.scale = scl.data_ptr() + offs[pos] * 2
@@ -404,18 +406,20 @@ class SweepPlan:
                     if nfed.value > 0:
                         fws = torch.empty(fws_b.value, dtype=torch.uint8, device=dev)
                         aux = torch.empty(aux_b.value, dtype=torch.uint8)
+                        tab_dev = torch.empty(host.numel(), dtype=torch.uint8, device=dev)   # (the brackets land in it)
                         sblocks = ctypes.c_int64(0)
                         fed_rows = (ctypes.c_int32 * n)()
                         rc = L.mq_sweep_feed_prepare(items, rows, cols, n, _DTYPES[dtype], ctypes.byref(cfg), self.pct,
-                                                     fws.data_ptr(), fws.numel(), host.data_ptr(), host.numel(),
-                                                     aux.data_ptr(), aux.numel(), ctypes.byref(seg_len),
+                                                     fws.data_ptr(), fws.numel(), tab_dev.data_ptr(), host.data_ptr(),
+                                                     host.numel(), aux.data_ptr(), aux.numel(), ctypes.byref(seg_len),
                                                      ctypes.byref(blocks), ctypes.byref(sblocks), ctypes.byref(nfed),
                                                      fed_rows)
                         if rc == _lib.OK:
                             frows = [fed_rows[j] for j in range(nfed.value)]
                             # (table, tensors, segment length, workgroups, dtype, aux, fed tensors, sampling workgroups,
                             #  feed workspace, fed rows of the table, their positions in the pass, results by table row)
-                            launches.append(("feedsweep", host.to(dev), n, seg_len.value, blocks.value, _DTYPES[dtype],
+                            tab_dev.copy_(host)
+                            launches.append(("feedsweep", tab_dev, n, seg_len.value, blocks.value, _DTYPES[dtype],
                                              aux.to(dev), nfed.value, sblocks.value, fws,
                                              torch.tensor(frows, dtype=torch.int64, device=dev),
                                              torch.tensor([poss[r] for r in frows], dtype=torch.int64, device=dev),
@@ -502,23 +506,30 @@ class SweepPlan:
                     fin = _side_streams[(dev.index, "fin")] = torch.cuda.Stream(device=dev)
                 fin.wait_stream(main)
             ws, _ = workspace(dev, self.ws_bytes)
-            # the sampling launches of pass k (fed lists: samples -> brackets) go to the second stream ahead of the
-            # selections of pass k - 1, so that they run beside the launches of pass k - 1
+            # the sampling launches of pass k (fed lists: samples -> brackets) run on a stream of their own beside the
+            # launches of pass k - 1 (behind the selections on the second stream they would hold up pass k)
+            pre = main
+            if overlap and any(la[0] == "feedsweep" for ps in self.plan for la in ps["launches"]):
+                pre = _side_streams.get((dev.index, "pre"))
+                if pre is None:
+                    pre = _side_streams[(dev.index, "pre")] = torch.cuda.Stream(device=dev)
+                pre.wait_stream(main)
+
             def sample(k):
                 ev = None
                 for la in self.plan[k]["launches"]:
                     if la[0] == "feedsweep":
                         _lib.check(L.mq_sweep_feed_sample(la[6].data_ptr(), la[7], la[3], la[8], la[5],
                                                           ctypes.byref(self.plan[k]["cfg"]), la[9].data_ptr(),
-                                                          side.cuda_stream))
+                                                          pre.cuda_stream))
                         ev = ev or torch.cuda.Event()
                 if ev is not None:
-                    ev.record(side)
+                    ev.record(pre)
                 return ev
             sampled = sample(0)
             for k, ps in enumerate(self.plan):
                 cfg = ps["cfg"]
-                if sampled is not None and side is not main:
+                if sampled is not None and pre is not main:
                     main.wait_event(sampled)
                 for la in ps["launches"]:
                     if la[0] == "npsweep":
@@ -551,9 +562,8 @@ class SweepPlan:
                             ps["p99"].index_copy_(0, sel["idx"], out)
                     for la in ps["launches"]:   # the fed lists: the wanted ranks among the kept entries
                         if la[0] == "feedsweep":
-                            _lib.check(L.mq_sweep_feed_finish(la[1].data_ptr(), la[2], la[6].data_ptr(), la[7], la[3], la[4],
-                                                              la[5], ctypes.byref(cfg), la[9].data_ptr(), la[12].data_ptr(),
-                                                              side.cuda_stream))
+                            _lib.check(L.mq_sweep_feed_finish(la[6].data_ptr(), la[7], la[3], la[8], la[5], ctypes.byref(cfg),
+                                                              la[9].data_ptr(), la[12].data_ptr(), side.cuda_stream))
                             ps["p99"].index_copy_(0, la[11], la[12][la[10]])
                     # the pass's rows of the record table (one launch: mean = sse / numel, NaN lists, row order)
                     _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
