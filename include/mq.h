@@ -197,6 +197,43 @@ int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t 
                  const mq_quant_cfg* cfg, int32_t seg_mse_f32, void* workspace, size_t workspace_bytes,
                  void* hip_stream);
 /*
+ * mq_sweep_run for per-group passes WITHOUT writing the lists of large tensors: the percentile of such a list
+ * (mse_p99 = np.percentile(vec, pct), quant_error_single_weight.py:79) is selected inside the pass.
+ *   mq_sweep_feed_sample  evaluates one wave step of every `unit` steps of each fed tensor (at most 1 / 16 of its
+ *                         weights, up to 32768 list entries) and takes two sample ranks, 12 binomial standard
+ *                         deviations either side of the wanted quantile, as the tensor's bracket;
+ *   mq_sweep_feed_run     is the pass: every wave counts its entries under the bracket and keeps the bit patterns of
+ *                         those inside it (plain stores into its own slot; no shared counter); the other tensors'
+ *                         lists are written as always;
+ *   mq_sweep_feed_finish  adds the counts, packs the kept entries and selects the two wanted ranks among them ->
+ *                         p99_out[table row] (float64, numpy's interpolation).  The counts are exact, so the result
+ *                         is the percentile of the list the pass would have written, bit for bit.  A bracket that does
+ *                         not hold both ranks, or a wave that kept more than it has room for, marks the tensor: the
+ *                         repair launch (a few microseconds when nothing is marked) writes its list after all and
+ *                         the percentile is selected from it.
+ * Fed: tensors whose list has a quarter of a million entries or so (mq_sweep_feed_sizes tells how many of `count`,
+ * and the bytes of feed_ws -- device, 256-byte aligned, one per pass -- and of aux).  mq_sweep_feed_prepare is
+ * mq_sweep_prepare plus the feed: table_dev is the DEVICE address the caller will copy table_host to (the brackets
+ * are written into it), aux_host receives the sampling launch's table and the selection jobs (copy it to the
+ * device: aux_dev), fed_rows[f] the table row of the f-th fed tensor.  MQ_ERR_UNSUPPORTED when no tensor is fed.
+ * Order: sample (any stream) -> run -> finish (any stream), each behind the one before.  No counterpart in the
+ * reference, which holds every list in host memory.
+ */
+int mq_sweep_feed_sizes(const int64_t* rows, const int64_t* cols, int32_t count, const mq_quant_cfg* cfg, double pct,
+                        int32_t* nfed, size_t* feed_ws_bytes, size_t* aux_bytes);
+int mq_sweep_feed_prepare(const mq_quant_item* items, const int64_t* rows, const int64_t* cols, int32_t count,
+                          int32_t w_dtype, const mq_quant_cfg* cfg, double pct, void* feed_ws_dev, size_t feed_ws_bytes,
+                          void* table_dev, void* table_host, size_t table_bytes, void* aux_host, size_t aux_bytes,
+                          int64_t* seg_len, int64_t* total_blocks, int64_t* sample_blocks, int32_t* nfed,
+                          int32_t* fed_rows);
+int mq_sweep_feed_sample(const void* aux_dev, int32_t nfed, int64_t seg_len, int64_t sample_blocks, int32_t w_dtype,
+                         const mq_quant_cfg* cfg, void* feed_ws_dev, void* hip_stream);
+int mq_sweep_feed_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
+                      const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
+int mq_sweep_feed_finish(const void* aux_dev, int32_t nfed, int64_t seg_len, int64_t sample_blocks, int32_t w_dtype,
+                         const mq_quant_cfg* cfg, void* feed_ws_dev, double* p99_out, void* hip_stream);
+
+/*
  * The same pass with every number of a report row in numpy's bits, at the speed of the pass above: per tensor
  *   the float32 per-vector list   per_vec[i] = compute_mse(slice)       quant_error_single_weight.py:56-71
  *   mse_tensor = float(np.mean((a32 - b32) ** 2)), float32              quant_error_multi_weight.py:55-58

@@ -260,11 +260,14 @@ class SweepPlan:
     0).  lists(k) -> the float32 per-vector MSE lists of pass k, in the order of `weights`.  Records and lists live in
     buffers of the plan: the next run() overwrites them.
 
-    feed_lists (default): in per-group passes the list of a large tensor (a quarter of a million entries and more) is
-    NOT written -- a sampling launch gives the tensor a bracket around the wanted quantile, the pass counts the entries
+    feed_lists: in per-group passes the list of a large tensor (a quarter of a million entries and more) is NOT
+    written -- a sampling launch gives the tensor a bracket around the wanted quantile, the pass counts the entries
     under it and keeps those inside, and the percentile is selected among the kept ones (exact: the sample only decides
     where to look; a bracket that misses makes the repair launch write the list after all).  lists(k) of such a tensor
-    then holds nothing: pass feed_lists=False when the lists themselves are wanted (plan.fed(k) tells which).
+    then holds nothing (plan.fed(k) tells which).  It removes the list's stores and the selection's re-reads (0.94 GB
+    each way per g = 32 pass of Llama-3-8B) but not time: measured on MI355X the pass alone gets 4 - 6 % shorter and
+    the whole step stays where it was -- the per-entry bookkeeping costs the issue-bound kernel about what the stores
+    did -- so it is off by default.
 
     Per pass ONE fused launch takes every layer whose segments have one length, whatever the shapes (mq_sweep_run:
     per-group passes the whole model, per-channel passes the layers of one column count; statistics only, float32
@@ -277,7 +280,7 @@ class SweepPlan:
     in `mse_tensor` [len(passes), len(weights)] then have the reference's bits."""
 
     def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True,
-                 feed_lists: bool = True):
+                 feed_lists: bool = False):
         import ctypes
         import os
         from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
@@ -309,8 +312,8 @@ class SweepPlan:
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
             single_launch = False
-        if os.environ.get("MQ_SWEEP_FEED", "1") == "0":     # (measurements with every list written)
-            feed_lists = False
+        if os.environ.get("MQ_SWEEP_FEED") in ("0", "1"):   # (measurements either way)
+            feed_lists = os.environ["MQ_SWEEP_FEED"] == "1"
         for datatype, bits, group_size in self.passes:
             fmt, table = format_code(datatype)
             if table in TABLE_LISTS:
@@ -652,8 +655,7 @@ def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = Non
     weights, passes = list(weights), list(passes)
     if numpy_order is None:
         numpy_order = numpy_order_available(weights, passes)
-    # (with vecs_of every list is written; otherwise the percentile of a large tensor's list is selected inside the pass)
-    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order, feed_lists=vecs_of is None)
+    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order)
     out = plan.run()
     res = [out]
     if vecs_of is not None:

@@ -488,8 +488,8 @@ def test_list_percentile_selected_inside_the_pass(dist):
     ws = _feed_weights(dist)
     ws[1][7, :64] = float("nan")                       # a tensor whose list holds a NaN: mse_p99 is NaN either way
     passes = [("int8", 8, 32), ("int8_asym", 8, 64), ("fp8_e4m3", 8, 32), ("int8", 8, 128), ("int8", 8, None), ("fp4", 4, 64)]
-    fed = report.SweepPlan(ws, passes)
-    ref = report.SweepPlan(ws, passes, feed_lists=False)
+    fed = report.SweepPlan(ws, passes, feed_lists=True)
+    ref = report.SweepPlan(ws, passes)
     assert bool(fed.fed(0)[:2].all()) and bool(fed.fed(0)[3]) and not bool(fed.fed(0)[2]) and not bool(fed.fed(0)[4])
     assert not bool(fed.fed(4).any()) and not bool(ref.fed(0).any())       # rows are never fed
     assert bool(fed.fed(1)[3])                                            # g = 64: the large tensors
@@ -515,8 +515,8 @@ def test_list_percentile_survives_a_misleading_sample():
     step = c * np.uint64(unit) + (((c * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(8)) % np.uint64(unit)
     w.view(-1, 2048)[torch.from_numpy(step.astype(np.int64)).cuda()] = 0
     other = (torch.randn(2048, 4096, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
-    fed = report.SweepPlan([w, other], [("int8", 8, gs)])
-    ref = report.SweepPlan([w, other], [("int8", 8, gs)], feed_lists=False)
+    fed = report.SweepPlan([w, other], [("int8", 8, gs)], feed_lists=True)
+    ref = report.SweepPlan([w, other], [("int8", 8, gs)])
     assert bool(fed.fed(0).all())
     a, b = fed.run().clone(), ref.run().clone()
     torch.cuda.synchronize()
