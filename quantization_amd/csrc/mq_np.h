@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
   };
   // the parameters of the group this lane computes (group m / T of the leaf); false: some group of the wave's step
   // is off the fast path
-  auto params = [&](const uint32_t* W, SegP& sp) __attribute__((always_inline)) {
+  auto params = [&](const uint32_t* W, SegP& sp, uint32_t& zpb) __attribute__((always_inline)) {
     uint32_t red[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -256,10 +256,35 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
 #pragma unroll
     for (int g = 1; g < NG; ++g) mine = (m / T) == g ? red[g] : mine;
     sp = stats_params<FMT>(mine, p);
+    zpb = h_bits(sp.zp);
+    if constexpr (FMT == MQ_INT_ASYM && T == 1) {
+      // the sign of a zero zero-point of a 32-element group (see zp_bits_first_zero): lane m holds word m of every
+      // vector, elements 8 (k % 4) + 2 m and + 1 of group k / 4
+      const bool need = zpb == 0u && (mine & 0xffffu) == 0x8000u;
+      if (p.zp && __builtin_amdgcn_ballot_w64(need) != 0ull) {
+        bool plus_first = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          uint32_t fp = 0xffffu, fm = 0xffffu;
+#pragma unroll
+          for (int k = WPG - 1; k >= 0; --k) {
+            const uint32_t w = W[g * WPG + k], e0 = (uint32_t)(8 * k + 2 * m);
+            fp = (w >> 16) == 0u ? e0 + 1u : fp;
+            fm = (w >> 16) == 0x8000u ? e0 + 1u : fm;
+            fp = (w & 0xffffu) == 0u ? e0 : fp;
+            fm = (w & 0xffffu) == 0x8000u ? e0 : fm;
+          }
+          fp = op_min_u32(fp, dpp<DPP_XOR1>(fp)); fp = op_min_u32(fp, dpp<DPP_XOR2>(fp));
+          fm = op_min_u32(fm, dpp<DPP_XOR1>(fm)); fm = op_min_u32(fm, dpp<DPP_XOR2>(fm));
+          plus_first = m == g ? fp < fm : plus_first;
+        }
+        zpb = (need && plus_first) ? 0x8000u : zpb;
+      }
+    }
     return __builtin_amdgcn_ballot_w64(sp.slow) == 0ull;
   };
   // entries, leaf sum, parameters -> memory
-  auto store = [&](int64_t t, const SegP& sp, const float* ent, float leaf, float ab) __attribute__((always_inline)) {
+  auto store = [&](int64_t t, const SegP& sp, uint32_t zpb, const float* ent, float leaf, float ab) __attribute__((always_inline)) {
     const int64_t lf = t * 16 + q;
     float mine = ent[0];
 #pragma unroll
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
     }
     if ((m % T) == 0) {  // the lane that computed group m / T's parameters
       if (p.scale) p.scale[lf * NG + m / T] = (uint16_t)h_bits(sp.s);
-      if (FMT == MQ_INT_ASYM && p.zp) p.zp[lf * NG + m / T] = (uint16_t)h_bits(sp.zp);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[lf * NG + m / T] = (uint16_t)zpb;
     }
     if (m == 0) {
       if (p.leaf) p.leaf[lf] = leaf;
@@ -281,7 +306,8 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
     uint32_t W[16];
     exchange(buf, W);
     SegP sp;
-    if (!params(W, sp)) { seen_slow = true; return; }
+    uint32_t zpb;
+    if (!params(W, sp, zpb)) { seen_slow = true; return; }
     const NpSeg own = np_seg<FMT>(sp);
     NpSeg G[NG];
     if constexpr (NG == 1) { G[0] = own; }
@@ -307,7 +333,7 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
       if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     const float leaf = NG == 1 ? ent[0] : np_quad_tree(flo + fhi);
-    store(t, sp, ent, leaf, ab);
+    store(t, sp, zpb, ent, leaf, ab);
   };
   {
     u32x4 bufa[4], bufb[4];
@@ -333,7 +359,8 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
       uint32_t W[16];
       exchange(buf, W);
       SegP sp;
-      if (params(W, sp)) continue;
+      uint32_t zpb;
+      if (params(W, sp, zpb)) continue;
       const NpSeg own = np_seg<FMT>(sp);
       float flo = 0.f, fhi = 0.f, ab = 0.f;
       float ent[NG];
@@ -357,7 +384,7 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
         ent[g] = np_quad_tree(rlo + rhi);
       }
       const float leaf = NG == 1 ? ent[0] : np_quad_tree(flo + fhi);
-      store(t, sp, ent, leaf, ab);
+      store(t, sp, zpb, ent, leaf, ab);
     }
   }
   block_partials(p, acc_sse, acc_abs, lds);

@@ -467,6 +467,44 @@ __device__ __forceinline__ SegP params_minmax(uint32_t mm, const QuantParams& p)
   return sp;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The sign of a zero zero-point.  zero-point = clamp(round(-rmin / scale)) is a zero when the segment's minimum is
+// one, and it carries the sign of -rmin.  When a segment holds zeros of both signs torch.amin (quant_weight.py:757)
+// returns the one its reduction meets first: the first one in memory for segments of fewer than 64 elements, which
+// it walks in order.  (From 64 elements on the reduction runs through the vector lanes of the CPU and the winner
+// depends on their width; there -0 orders below +0 here, as in the packed minimum.)  The packed minimum always
+// prefers -0, so the only case to put right is "rmin = -0 although a +0 comes before the first -0": the zero-point
+// is -0 then.  No other output depends on it.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t op_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// index of the first +0 / first -0 among the 8 halves of a vector whose first element is element e0 of its segment
+__device__ __forceinline__ void first_zeros8(u32x4 v, uint32_t e0, uint32_t& fp, uint32_t& fm) {
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    const uint32_t h = (v[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+    fp = h == 0u ? e0 + (uint32_t)i : fp;
+    fm = h == 0x8000u ? e0 + (uint32_t)i : fm;
+  }
+}
+// -> the bits of the zero-point to store.  mm: the segment's (min, max) word; the segment is held by the T lanes of
+// a team, this lane's raw[j] being vector vec0 + j * vstep of it (holds: false for a lane without data).  Every
+// lane of the wave calls this together.
+template <int T, int NVV>
+__device__ __forceinline__ uint32_t zp_bits_first_zero(const SegP& sp, uint32_t mm, const u32x4* raw, int vec0, int vstep,
+                                                        bool holds, int64_t L) {
+  const uint32_t zb = h_bits(sp.zp);
+  const bool need = zb == 0u && (mm & 0xffffu) == 0x8000u && L < 64;
+  if (__builtin_amdgcn_ballot_w64(need) == 0ull) return zb;
+  uint32_t fp = 0xffffu, fm = 0xffffu;
+  if (holds) {
+#pragma unroll
+    for (int j = NVV - 1; j >= 0; --j) first_zeros8(raw[j], (uint32_t)(vec0 + j * vstep) * 8u, fp, fm);
+  }
+  fp = team_reduce_u32<T>(fp, op_min_u32);
+  fm = team_reduce_u32<T>(fm, op_min_u32);
+  return (need && fp < fm) ? 0x8000u : zb;
+}
+
 // Nearest value of an (E, M, bias) table for x given as float16 (or float32) bits: round the mantissa
 // to M bits (ties toward -inf: down in magnitude for x > 0, up for x < 0), saturate at the largest
 // entry, and below the smallest positive entry choose between it and 0 at their midpoint.  NaN -> +0.
@@ -1001,11 +1039,17 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       SegP sp;
+      uint32_t zpb = 0;
       if constexpr (FMT == MQ_INT_ASYM) {
         uint32_t lo, hi;
         minmax8_pk(raw[j], lo, hi);
         uint32_t mm = valid[j] ? fold_minmax(lo, hi) : 0xfc007c00u;  // (+inf, -inf): neutral
-        sp = params_minmax(team_reduce_u32<T>(mm, op_minmax), p);
+        mm = team_reduce_u32<T>(mm, op_minmax);
+        sp = params_minmax(mm, p);
+        zpb = h_bits(sp.zp);
+        if constexpr (T <= 8) {
+          if (p.zp) zpb = zp_bits_first_zero<T, 1>(sp, mm, &raw[j], tl, 0, valid[j], p.L);
+        }
       } else {
         uint32_t m = fold_max_u16(absmax8_pk(raw[j]));
         sp = params_absmax(team_reduce_u32<T>(m, op_max_u32), p);
@@ -1020,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_quant_team(const QuantBatch b) {
       }
       if (valid[j] && tl == 0) {
         if (p.scale) p.scale[seg[j]] = (uint16_t)h_bits(sp.s);
-        if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg[j]] = (uint16_t)h_bits(sp.zp);
+        if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg[j]] = (uint16_t)zpb;
       }
     }
   }
@@ -1066,6 +1110,7 @@ __global__ __launch_bounds__(256) void k_quant_team4(const QuantBatch b) {
     for (int j = 0; j < NV; ++j) raw[j] = raw_to_f16(nxt[j], p.in_dtype);
     if (t + nwaves < steps) issue(t + nwaves, nxt);
     SegP sp;
+    uint32_t zpb = 0;
     if constexpr (FMT == MQ_INT_ASYM) {
       uint32_t mm = 0xfc007c00u;  // (+inf, -inf): neutral
 #pragma unroll
@@ -1074,7 +1119,12 @@ __global__ __launch_bounds__(256) void k_quant_team4(const QuantBatch b) {
         minmax8_pk(raw[j], lo, hi);
         if (valid) mm = op_minmax(mm, fold_minmax(lo, hi));
       }
-      sp = params_minmax(team_reduce_u32<T>(mm, op_minmax), p);
+      mm = team_reduce_u32<T>(mm, op_minmax);
+      sp = params_minmax(mm, p);
+      zpb = h_bits(sp.zp);
+      if constexpr (T == 1) {  // (32 elements: the lane's four vectors in memory order)
+        if (p.zp) zpb = zp_bits_first_zero<1, NV>(sp, mm, raw, 0, 1, valid, p.L);
+      }
     } else {
       uint32_t m2 = 0;
 #pragma unroll
@@ -1093,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_quant_team4(const QuantBatch b) {
     }
     if (valid && tl == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
-      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)zpb;
     }
   }
   block_partials(p, acc_sse, acc.abs, lds);
@@ -1505,7 +1555,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
       r[0][k] = e[0]; r[1][k] = e[1]; r[2][k] = f[0]; r[3][k] = f[1];
     }
   };
-  auto finish = [&](int64_t t, const SegP& sp, double s, double ab, bool take, const float (*sq)[8]) __attribute__((always_inline)) {
+  auto finish = [&](int64_t t, const SegP& sp, uint32_t zpb, double s, double ab, bool take, const float (*sq)[8]) __attribute__((always_inline)) {
     const int64_t seg = t * SPW + team;
     const bool valid = (t < full || seg < p.nseg) && take;
     s = take ? s : 0.0;
@@ -1539,8 +1589,16 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     }
     if (valid && tl == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
-      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)zpb;
     }
+  };
+  // the zero-point to store (32-element segments: the lane's four vectors are the segment, in memory order)
+  auto zp_of = [&](const SegP& sp, uint32_t red, const u32x4* raw) __attribute__((always_inline)) {
+    uint32_t zpb = h_bits(sp.zp);
+    if constexpr (FMT == MQ_INT_ASYM && T == 1 && TR) {
+      if (p.zp) zpb = zp_bits_first_zero<1, NV>(sp, red, raw, 0, 1, true, p.L);
+    }
+    return zpb;
   };
   auto step = [&](int64_t t, const u32x4* buf) __attribute__((always_inline)) {
     u32x4 raw[NV];
@@ -1549,16 +1607,18 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
     transpose(raw);
 #pragma unroll
     for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
-    const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
+    const uint32_t red = team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>);
+    const SegP sp = stats_params<FMT>(red, p);
+    const uint32_t zpb = zp_of(sp, red, raw);
     seen_slow = seen_slow || sp.slow;
     double s, ab;
     if constexpr (EXACT) {
       float sq[NV][8];
       stats_vectors<FMT, NV, true>(p, raw, sp, s, ab, sq);
-      finish(t, sp, s, ab, !sp.slow, sq);
+      finish(t, sp, zpb, s, ab, !sp.slow, sq);
     } else {
       stats_vectors<FMT, NV>(p, raw, sp, s, ab);  // (a lane past the end holds zeros: no error)
-      finish(t, sp, s, ab, !sp.slow, nullptr);
+      finish(t, sp, zpb, s, ab, !sp.slow, nullptr);
     }
   };
   // two register buffers take turns, so that the next step's loads are in flight while this one is computed and
@@ -1585,8 +1645,10 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
       transpose(raw);
 #pragma unroll
       for (int j = 0; j < NV; ++j) raw[j] = stats_cvt<BF16>(raw[j]);
-      const SegP sp = stats_params<FMT>(team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>), p);
+      const uint32_t red = team_reduce_u32<T>(stats_lane_reduce<FMT, NV>(raw), stats_op<FMT>);
+      const SegP sp = stats_params<FMT>(red, p);
       if (__builtin_amdgcn_ballot_w64(sp.slow) == 0) continue;
+      const uint32_t zpb = zp_of(sp, red, raw);
       double s = 0.0, ab = 0.0;
       float sq[NV][8];
       if constexpr (EXACT) {
@@ -1599,7 +1661,7 @@ __global__ __launch_bounds__(256) void k_stats_group(const QuantBatch b) {
         stats_slow_segment<FMT>(p, sp, wb + step_of(t) * 4096 + (TR ? lane * 64 : (int)loff),
                                 (t < full || t * SPW + team < p.nseg) ? NV : 0, TR ? 16 : 16 * T, s, ab,
                                 EXACT ? sq : nullptr);
-      finish(t, sp, s, ab, sp.slow, sq);
+      finish(t, sp, zpb, s, ab, sp.slow, sq);
     }
   }
   if constexpr (!EXACT) {
@@ -2132,7 +2194,16 @@ __global__ __launch_bounds__(256) void k_quant_generic(const QuantBatch b) {
     }
     if (threadIdx.x == 0) {
       if (p.scale) p.scale[seg] = (uint16_t)h_bits(sp.s);
-      if (FMT == MQ_INT_ASYM && p.zp) p.zp[seg] = (uint16_t)h_bits(sp.zp);
+      if (FMT == MQ_INT_ASYM && p.zp) {
+        uint32_t zpb = h_bits(sp.zp);
+        if (zpb == 0u && (mm & 0xffffu) == 0x8000u && p.L < 64) {  // (see zp_bits_first_zero)
+          for (int64_t i = 0; i < p.L; ++i) {
+            const uint32_t vb = load1_f16(p.w, p.in_dtype, base + i);
+            if ((vb & 0x7fffu) == 0u) { zpb = vb == 0u ? 0x8000u : 0u; break; }
+          }
+        }
+        p.zp[seg] = (uint16_t)zpb;
+      }
     }
     parity ^= 1;
   }

@@ -35,6 +35,11 @@ def run(budget, seed):
         if kind == 3: w[rng.integers(rows), rng.integers(cols)] = float("nan")
         if kind == 4: w[:, rng.integers(cols)] = -scale * 40
         if kind == 5: w = torch.from_numpy(rng.standard_t(3, (rows, cols)).astype(np.float32)) * scale
+        if kind == 6:   # non-negative rows with zeros of both signs: the sign of a zero zero-point
+            w = w.abs()
+            zs = torch.from_numpy(rng.random((rows, cols)) < 0.3)
+            w[zs] = 0.0
+            w[zs & torch.from_numpy(rng.random((rows, cols)) < 0.5)] = -0.0
         wt = {"f16": w.half(), "bf16": w.bfloat16(), "f32": w}[dt]
         if name.startswith("int"):
             asym = "asym" in name
@@ -58,12 +63,9 @@ def run(budget, seed):
             raise AssertionError(what + " deq")
         assert gu.same_f16_bits(bits16(res.scale).reshape(-1), exp["scale"].reshape(-1)), what + " scale"
         if "asym" in name:
-            # (the sign of a ZERO zero-point is left out: it is the sign of -min of a segment whose minimum is a zero,
-            #  and with zeros of both signs in the segment torch.amin returns whichever its reduction order meets --
-            #  the first one up to 32 elements, a lane-dependent one beyond; the kernels order -0 below +0)
+            # (the sign of a zero zero-point included: the first zero in memory decides it below 64 elements, -0 orders
+            #  below +0 from there on -- in the kernels as in the oracle)
             g_, e_ = bits16(res.zero_point).reshape(-1).copy(), exp["zp"].reshape(-1).copy()
-            g_[g_ == 0x8000] = 0
-            e_[e_ == 0x8000] = 0
             if not gu.same_f16_bits(g_, e_):
                 L_ = rows * cols if gs == -1 else (gs or cols)
                 for i in np.nonzero(g_ != e_)[0][:6]:

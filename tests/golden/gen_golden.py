@@ -25,6 +25,9 @@ Files written:
                         nn.Sequential of four float16 nn.Linear: weights before / after, every registered buffer
                         (bytes, dtype, shape) and the module class names, for int8 / int8_asym / int4_asym /
                         fp8_e4m3 / fp4 x {per-channel, g=64, per-tensor}
+  quant_zero_sign.npz   int8_asym / int4_asym on rows whose minimum is a zero, with zeros of both signs in every segment
+                        (g = 8 / 16 / 32 / 64 / 128, per-channel, per-tensor): which zero torch.amin returns decides the
+                        sign of a zero zero-point
   onnx/                 model files written by PyTorch's ONNX serializer (plain and quantized by the reference's
                         quant_model), every parameter's bits, the MatMul / Gemm weight names
   search_errors.json    what search_datatype raises for weights that are not float16
@@ -341,6 +344,40 @@ def gen_specials():
     print("quant_specials.npz", len(arrays), "arrays")
 
 
+def gen_zero_sign():
+    """Segments whose minimum is a zero and that hold +0 and -0: _int_quant_meta takes rmin = w.amin(-1)
+    (quant_weight.py:179-183) and zero-point = clamp(round(-rmin / scale)), so the zero amin returns gives the sign of
+    the zero-point.  torch's reduction meets up to 32 elements in memory order (the first zero wins: 200 of 200 trials
+    per length, checked when this was written); longer segments go through vector lanes and the winner depends on the
+    positions."""
+    gen = torch.Generator().manual_seed(77)
+    rows, cols = 64, 256
+    w = (torch.randn(rows, cols, generator=gen).abs() * 0.02 + 0.001).half()
+    sign = torch.randint(0, 2, (rows, cols), generator=gen).bool()
+    place = torch.rand(rows, cols, generator=gen) < 0.3
+    w[place & sign] = 0.0
+    w[place & ~sign] = -0.0
+    for r in range(rows):                       # every segment of 8 holds both zeros, in either order
+        for c in range(0, cols, 8):
+            i, j = torch.randperm(8, generator=gen)[:2].tolist()
+            w[r, c + i], w[r, c + j] = 0.0, -0.0
+    w[48:56] = torch.where(w[48:56] == 0, w[48:56], -w[48:56])      # all-negative rows: the maximum is the zero
+    w[56:, ::5] = -w[56:, ::5].abs() - 0.004                           # rows where the zeros are not the extreme
+    arrays = {"in": bits16(w)}
+    for bits in (8, 4):
+        for gs in [8, 16, 32, 64, 128, None, -1]:
+            d, q, s, zp = qw._int_quant_meta(w, wq_bits=bits, asym=True, group_size=gs)
+            d2, q2, s2, zp2 = qw._int_quant_meta(w.clone(), wq_bits=bits, asym=True, group_size=gs)
+            pre = f"out/int{bits}_asym/{gs_key(gs)}/"
+            arrays[pre + "deq"] = bits16(d)
+            arrays[pre + "q"] = q.contiguous().view(torch.uint8).numpy().copy()
+            arrays[pre + "scale"] = bits16(s.reshape(-1))
+            arrays[pre + "zp"] = bits16(zp.reshape(-1))
+            arrays[pre + "zp_again"] = bits16(zp2.reshape(-1))     # a second call on a copy at another address
+    np.savez_compressed(os.path.join(HERE, "quant_zero_sign.npz"), **arrays)
+    print("quant_zero_sign.npz", len(arrays), "arrays")
+
+
 MIXED = ["mixed_bitmod", "mixed_er", "mixed_ea", "mixed_ant"]
 
 
@@ -612,6 +649,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "specials":
         gen_specials()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "zero_sign":
+        gen_zero_sign()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "api":
         gen_api_errors()
         sys.exit(0)
@@ -630,6 +670,7 @@ if __name__ == "__main__":
     gen_table_formats()
     gen_search()
     gen_specials()
+    gen_zero_sign()
     gen_quant_model()
     gen_quant_small()
     gen_exhaustive()

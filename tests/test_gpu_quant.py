@@ -556,3 +556,127 @@ def test_fused_p99_wide_bracket_with_per_element_segments():
     r = subprocess.run([sys.executable, "-c", _SLOW_FEED_SCRIPT, root], env=dict(os.environ, MQ_MAX_BLOCKS="8"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _zero_sign_inputs(rows, cols, seed):
+    """Non-negative rows with zeros of both signs in (nearly) every group of 4 elements; some rows with negatives."""
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(rows, cols, generator=g).abs() * 0.02 + 0.001
+    zs = torch.rand(rows, cols, generator=g) < 0.35
+    neg = torch.rand(rows, cols, generator=g) < 0.5
+    w[zs & neg] = -0.0
+    w[zs & ~neg] = 0.0
+    if rows > 3:
+        w[rows - 1, ::7] = -0.01          # the zeros are not the minimum there
+        w[rows - 2] = -w[rows - 2]        # all <= 0: the zeros are the maximum
+    return w
+
+
+def _bits16(t):
+    return t.contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def test_zero_point_sign_of_zero_golden():
+    """The imported reference's outputs on segments whose minimum is a zero and that hold +0 and -0
+    (tests/golden/quant_zero_sign.npz): below 64 elements torch.amin returns the first zero in memory and the
+    zero-point's zero carries the opposite sign -- compared bit for bit, through the general kernels (every output)
+    and through the statistics-only kernels; from 64 elements on the sign of a zero zero-point is left out (the
+    reference's choice there depends on the vector lanes of the CPU that ran it)."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    z = gu.npz("quant_zero_sign.npz")
+    w = z["in"]
+    wt = torch.from_numpy(w.view(np.int16).copy()).view(torch.float16).cuda()
+    for bits in (8, 4):
+        for gs in (8, 16, 32, 64, 128, None, -1):
+            pre = f"out/int{bits}_asym/{gu.gs_key(gs)}/"
+            L = w.size if gs == -1 else (gs or w.shape[1])
+            full = quantize(wt, _lib.INT_ASYM, bits, gs, None, deq=True, codes=True, scale=True)
+            stat = quantize(wt, _lib.INT_ASYM, bits, gs, None, deq=False, codes=False, scale=True, totals=True)
+            assert np.array_equal(_bits16(full.deq).reshape(-1), z[pre + "deq"].reshape(-1)), (bits, gs)
+            assert np.array_equal(full.codes.cpu().numpy().reshape(-1), z[pre + "q"].reshape(-1)), (bits, gs)
+            for res in (full, stat):
+                assert np.array_equal(_bits16(res.scale), z[pre + "scale"]), (bits, gs)
+                got, want = _bits16(res.zero_point).copy(), z[pre + "zp"].copy()
+                if L >= 64:
+                    got[got == 0x8000] = 0
+                    want[want == 0x8000] = 0
+                assert np.array_equal(got, want), (bits, gs, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16", "f32"])
+def test_zero_point_sign_of_zero_every_kernel(oracle, dt):
+    """The same rule against the oracle (which the CPU suite pins to the reference's fixture), bit for bit at EVERY
+    segment length -- first zero in memory below 64 elements, -0 below +0 from there on -- through each kernel that
+    stores zero-points: sub-wave teams (8 .. 56 elements), the generic kernel (lengths that are not a multiple of 8,
+    unaligned rows), the four-vectors-per-lane statistics kernels (32 elements; float32 weights take the other one),
+    rows, per-tensor."""
+    from quantization_amd import _lib
+    from quantization_amd.fused import quantize
+    odt = {"f16": oracle.F16, "bf16": oracle.BF16, "f32": oracle.F32}[dt]
+    cases = [(24, 1024, 8), (24, 1024, 16), (24, 960, 24), (24, 1024, 32), (24, 960, 40), (24, 960, 48), (24, 1008, 56),
+             (24, 1024, 64), (24, 1024, 128), (16, 1000, 4), (16, 1000, 20), (16, 1000, 50), (16, 999, 27), (16, 999, 37),
+             (24, 2048, None), (8, 333, None), (5, 40, None), (8, 512, -1), (37, 32, 32), (3, 24, None)]
+    for k, (rows, cols, gs) in enumerate(cases):
+        w = _zero_sign_inputs(rows, cols, 500 + k)
+        wt = {"f16": w.half(), "bf16": w.bfloat16(), "f32": w}[dt]
+        raw = wt.numpy() if dt == "f32" else wt.view(torch.int16).numpy().view(np.uint16)
+        for bits in (8, 3):
+            exp = oracle.quantize(raw, odt, group_size=gs, fmt=oracle.INT_ASYM, bits=bits)
+            calls = [dict(deq=True, codes=True, scale=True), dict(deq=False, codes=False, scale=True, totals=True),
+                     dict(deq=False, codes=False, scale=True, seg_sse=True)]
+            for kw in calls:
+                res = quantize(wt.cuda(), _lib.INT_ASYM, bits, gs, None, **kw)
+                got = _bits16(res.zero_point)
+                assert np.array_equal(got, exp["zp"]), (dt, rows, cols, gs, bits, sorted(kw), int((got != exp["zp"]).sum()))
+                assert np.array_equal(_bits16(res.scale), exp["scale"])
+                if kw.get("deq"):
+                    assert np.array_equal(_bits16(res.deq).reshape(-1), exp["deq"].reshape(-1))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_zero_point_sign_of_zero_numpy_order_launch(oracle, dt):
+    """... and through the numpy-order sweep launch (32-element groups: a quad of lanes shares the group's words)."""
+    import ctypes
+    from quantization_amd import _lib
+    from quantization_amd.fused import _DTYPES, _QuantItem, bind_batch, make_cfg, workspace
+    L = bind_batch()
+    shapes = [(16, 1024), (8, 2048), (4, 8192)]
+    ws_ = [_zero_sign_inputs(r, c, 600 + i) for i, (r, c) in enumerate(shapes)]
+    wts = [(w.half() if dt == "f16" else w.bfloat16()).cuda() for w in ws_]
+    cfg = make_cfg(_lib.INT_ASYM, 8, 32, None)
+    n = len(wts)
+    items = (_QuantItem * n)()
+    keep = []
+    for j, wt in enumerate(wts):
+        nseg = wt.numel() // 32
+        ent = torch.empty(nseg, dtype=torch.float32, device="cuda")
+        sc = torch.empty(nseg, dtype=torch.float16, device="cuda")
+        zp = torch.empty(nseg, dtype=torch.float16, device="cuda")
+        tot = torch.zeros(2, dtype=torch.float64, device="cuda")
+        keep.append((ent, sc, zp, tot))
+        items[j].w = wt.data_ptr()
+        o = items[j].out
+        o.abs_err_dtype = _lib.F32
+        o.seg_mse_f32 = 2
+        o.seg_sse, o.scale, o.zero_point, o.totals = ent.data_ptr(), sc.data_ptr(), zp.data_ptr(), tot.data_ptr()
+    rows = (ctypes.c_int64 * n)(*[s[0] for s in shapes])
+    cols = (ctypes.c_int64 * n)(*[s[1] for s in shapes])
+    leaf = torch.empty(sum(w.numel() // 128 for w in wts), dtype=torch.float32, device="cuda")
+    host = torch.empty(L.mq_sweep_numpy_table_bytes(n), dtype=torch.uint8)
+    seg_len, blocks, tl, lc = (ctypes.c_int64(0) for _ in range(4))
+    _lib.check(L.mq_sweep_numpy_prepare(items, rows, cols, n, _DTYPES[wts[0].dtype], ctypes.byref(cfg), leaf.data_ptr(),
+                                        host.data_ptr(), host.numel(), ctypes.byref(seg_len), ctypes.byref(blocks),
+                                        ctypes.byref(tl), ctypes.byref(lc)))
+    tab = host.cuda()
+    ws, stream = workspace(torch.device("cuda:0"), L.mq_sweep_workspace_bytes(blocks.value))
+    _lib.check(L.mq_sweep_numpy_run(tab.data_ptr(), n, seg_len.value, blocks.value, _DTYPES[wts[0].dtype], ctypes.byref(cfg),
+                                    ws.data_ptr(), ws.numel(), stream.cuda_stream))
+    torch.cuda.synchronize()
+    odt = oracle.F16 if dt == "f16" else oracle.BF16
+    for wt, (ent, sc, zp, tot) in zip(wts, keep):
+        raw = wt.cpu().view(torch.int16).numpy().view(np.uint16)
+        exp = oracle.quantize(raw, odt, group_size=32, fmt=oracle.INT_ASYM, bits=8)
+        assert (exp["zp"] == 0x8000).sum() > 10 and (exp["zp"] == 0).sum() > 10
+        assert np.array_equal(_bits16(zp), exp["zp"]), int((_bits16(zp) != exp["zp"]).sum())
+        assert np.array_equal(_bits16(sc), exp["scale"])

@@ -67,6 +67,32 @@ def test_special_rows(oracle, fmt, gs):
         assert gu.same_f16_bits(out["q"].reshape(-1)[ok], exp["q"].reshape(-1)[ok]), "codes"
 
 
+@pytest.mark.parametrize("bits", [8, 4])
+@pytest.mark.parametrize("gs", [8, 16, 32, 64, 128, None, -1], ids=gu.gs_key)
+def test_zero_point_sign_of_zero(oracle, bits, gs):
+    """Segments whose minimum is a zero and that hold +0 and -0 (quant_zero_sign.npz, from the imported reference):
+    everything bit for bit; the zero-point's zero carries the sign of -(first zero in memory) for segments of fewer
+    than 64 elements.  From 64 elements on torch.amin's choice depends on the vector lanes of the CPU that ran it
+    (the fixture shows about half of the segments following the first-in-memory rule): there the sign of a zero
+    zero-point is left out of the comparison, and only there."""
+    z = gu.npz("quant_zero_sign.npz")
+    w = z["in"]
+    pre = f"out/int{bits}_asym/{gu.gs_key(gs)}/"
+    out = oracle.quantize(w, oracle.F16, group_size=gs, fmt=oracle.INT_ASYM, bits=bits)
+    assert np.array_equal(out["deq"].reshape(-1), z[pre + "deq"].reshape(-1))
+    assert np.array_equal(out["q"].reshape(-1), z[pre + "q"].reshape(-1))
+    assert np.array_equal(out["scale"], z[pre + "scale"])
+    assert np.array_equal(z[pre + "zp"], z[pre + "zp_again"])
+    got, want = out["zp"].copy(), z[pre + "zp"].copy()
+    L = w.size if gs == -1 else (gs or w.shape[1])
+    if L < 64:
+        assert (want == 0x8000).sum() > 50 and (want == 0).sum() > 50   # both signs occur
+    else:
+        got[got == 0x8000] = 0
+        want[want == 0x8000] = 0
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("fmt", ["fp8_e4m3", "fp8_e3m4"])
 def test_lut_domain_sweep(oracle, fmt):
     """Every float16 x with |x| <= LUTmax through the reference's LUT rounding (scale == 1)."""
