@@ -333,6 +333,35 @@ int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, int32_t w_d
                           void* hip_stream);
 
 /*
+ * Several mq_quantize_p99_batch passes over stacks of one shape -- the configurations of a sweep, e.g. the group
+ * sizes the reference's scripts loop over (elwise_error/onnx_error_cli.py:96-120 per configuration) -- enqueued
+ * together: pass k has its own items (outputs), configuration and results.  The results are those of npass separate
+ * mq_quantize_p99_batch calls; the difference is where the short kernels run: the chain in front of a full pass
+ * (sampling pass, sample histogram, bracket) and the one behind it (bracket scan, candidates, the guarded exact
+ * route) go to two streams the library owns, beside the neighbouring full passes, and the caller's stream carries the
+ * full passes back to back.  list_p99 (optional, device array of `count` doubles per pass): np.percentile(list_i,
+ * list_pct) of every item's float32 per-segment MSE list (items must then request seg_sse with seg_mse_f32 = 1), in
+ * float64 as mq_percentile_multi with MQ_F32_AS_F64, selected behind the pass as well.  The caller's stream waits for
+ * both library streams before the call returns, so everything enqueued on it afterwards sees every output.
+ * The kernels that need a CU to themselves (the guarded exact route, the list percentiles) run after the last full
+ * pass; when the p99 (and list_p99) arrays of consecutive passes follow each other in memory and count <= 32 they
+ * go through one set of launches for up to 64 arrays instead of one per pass.
+ * At most 24 (pass, 32-item chunk) pairs per call (MQ_ERR_UNSUPPORTED beyond).  workspace: 256-byte aligned.
+ * Calls on one device are serialised while they enqueue (the library streams and their events are shared).
+ * No counterpart in the reference (it runs one configuration after the other on the CPU).
+ */
+typedef struct mq_p99_pass {
+  const mq_quant_item* items; /* [count] */
+  const mq_quant_cfg* cfg;
+  float* p99;                 /* device [count] */
+  double* list_p99;           /* device [count], or NULL */
+} mq_p99_pass;
+size_t mq_quantize_p99_passes_workspace_bytes(int32_t npass, int32_t count, int64_t rows, int64_t cols);
+int mq_quantize_p99_passes(const mq_p99_pass* passes, int32_t npass, int32_t count, int32_t w_dtype, int64_t rows,
+                           int64_t cols, double pct, double list_pct, void* workspace, size_t workspace_bytes,
+                           void* hip_stream);
+
+/*
  * Value tables given as explicit lists: the reference's formats whose values have no (E, M, bias) closed form
  * (FP3 quant_weight.py:11, FLINT4 :20, FLINT5 :36, the FP3/FP4 *_er_* / *_ea_* lists :12-15, :24-31), FP8_E5M2
  * :139-169, whose path runs in float32 (:505-540, :796-826), and the MX path (quant_mx :337-380).

@@ -2607,6 +2607,7 @@ int mq_launch_np4(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatc
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
 // State of the calling thread: a pool of events that is created outside the timed region (mq_profile_reserve, or
 // on first use) and reused by every later mq_profile_begin; prof_used counts the events of the current run.
+#include <mutex>
 #include <vector>
 static thread_local bool prof_on = false;
 static thread_local std::vector<hipEvent_t> prof_pool;  // start, stop, start, stop, ...
@@ -2840,6 +2841,10 @@ static bool aligned(const void* q, size_t a) { return (reinterpret_cast<uintptr_
 // over the sampled tiles / rows only, with every output suppressed).  With `sampled` set nothing is launched:
 // it receives the number of elements per tensor the sampling pass would feed (0: this shape's kernels cannot
 // feed a selection).
+// Set around a call: the kernel that adds up the workgroups' partial sums goes to this stream, behind this event
+// recorded on the launch stream after the quantize kernel.
+static thread_local hipStream_t tl_totals_stream = nullptr;
+static thread_local hipEvent_t tl_totals_event = nullptr;
 static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_dtype, int64_t rows, int64_t cols,
                            const mq_quant_cfg* cfg, void* workspace, hipStream_t st, int sel_mode = SEL_FEED_OFF,
                            char* sel_ws = nullptr, int64_t* sampled = nullptr, uint16_t* samples = nullptr,
@@ -3023,8 +3028,15 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
   }
   MQ_HIP(hipGetLastError());
   if (timed) MQ_HIP(hipEventRecord(prof_e1, st));
+  hipStream_t fst = st;
+  if (tl_totals_stream && sel_mode != SEL_FEED_SAMPLE) {
+    // (see mq_quantize_p99_passes: whatever follows the quantize kernel goes to the second stream, behind this event)
+    MQ_HIP(hipEventRecord(tl_totals_event, st));
+    MQ_HIP(hipStreamWaitEvent(tl_totals_stream, tl_totals_event, 0));
+    fst = tl_totals_stream;
+  }
   if (sel_mode != SEL_FEED_SAMPLE && (o0.totals || (scope == SC_TENSOR && o0.seg_sse))) {
-    hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, st, b, (int)grid.x,
+    hipLaunchKernelGGL(k_finalize_totals, dim3((unsigned)count), dim3(256), 0, fst, b, (int)grid.x,
                        scope == SC_TENSOR ? 1 : 0);
     MQ_HIP(hipGetLastError());
   }
@@ -3386,6 +3398,196 @@ extern "C" int mq_quantize_p99_batch(const mq_quant_item* items, int32_t count, 
         return rc;
     }
   }
+  return MQ_OK;
+}
+// ---- several passes over same-shaped stacks enqueued together ---------------------------------------------
+// What a pass's selection needs in front of its full quantize pass (clear, sampling pass, sample histogram, bracket)
+// and behind it (bracket scan, candidates, guarded exact route, list percentile) is a chain of short dependent
+// kernels.  With the passes of a sweep known together:
+//  * the front chains of all passes run first, and the kernels that are per selection slice (clear, sample
+//    histogram, sample scan, bracket clear) take the slices of ALL passes in one launch each;
+//  * behind a full pass, the kernels with small workgroups (partial sums, bracket scan, candidates) go to a second,
+//    library-owned stream and run beside the next full pass, so the caller's stream carries the full passes back to
+//    back;
+//  * the kernels that need a CU to themselves (128 KiB histograms: the guarded exact route, the list percentiles)
+//    wait for the last full pass and again take all passes' slices per launch.
+// (Measured on 16 x 4096 x 4096 float16, three group sizes: front chains beside a full pass slowed it by as much as
+//  they took alone, and a 1024-thread / 128 KiB workgroup beside a full pass is not scheduled until that pass drains.)
+#define MQ_P99_MAX_UNITS 24
+namespace {
+struct PassStreams {
+  hipStream_t post = nullptr;
+  hipEvent_t done = nullptr, main_ev[MQ_P99_MAX_UNITS] = {};
+};
+std::mutex g_pass_mu;  // held while a call enqueues: the stream and events of a device are shared by its callers
+PassStreams* pass_streams(int* rc) {
+  static PassStreams per_dev[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *rc = MQ_ERR_HIP; return nullptr; }
+  PassStreams& ps = per_dev[dev];
+  if (!ps.post) {
+    hipStream_t a = nullptr;
+    if (hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { *rc = MQ_ERR_HIP; return nullptr; }
+    bool ok = hipEventCreateWithFlags(&ps.done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < MQ_P99_MAX_UNITS; ++i)
+      ok = hipEventCreateWithFlags(&ps.main_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { *rc = MQ_ERR_HIP; return nullptr; }
+    ps.post = a;
+  }
+  return &ps;
+}
+size_t pass_unit_bytes(int32_t c, int64_t rows, int64_t cols) {
+  return sel_slices_offset(c) + (size_t)c * sel_ws_bytes() + ((size_t)c * sample_stride_elems(rows * cols) * 2 + 255) / 256 * 256;
+}
+}  // namespace
+
+extern "C" size_t mq_quantize_p99_passes_workspace_bytes(int32_t npass, int32_t count, int64_t rows, int64_t cols) {
+  if (npass < 1 || count < 1) return 0;
+  const int64_t chunks = (count + MQ_MAX_BATCH - 1) / MQ_MAX_BATCH;
+  return (size_t)npass * (size_t)chunks * pass_unit_bytes(count < MQ_MAX_BATCH ? count : MQ_MAX_BATCH, rows, cols);
+}
+
+extern "C" int mq_quantize_p99_passes(const mq_p99_pass* passes, int32_t npass, int32_t count, int32_t w_dtype,
+                                      int64_t rows, int64_t cols, double pct, double list_pct, void* workspace,
+                                      size_t workspace_bytes, void* hip_stream) {
+  if (npass < 0 || count < 0 || rows < 0 || cols < 0 || (npass > 0 && !passes)) return MQ_ERR_ARG;
+  if (!(pct >= 0.0 && pct <= 100.0) || !(list_pct >= 0.0 && list_pct <= 100.0)) return MQ_ERR_ARG;
+  if (w_dtype != MQ_F16 && w_dtype != MQ_BF16 && w_dtype != MQ_F32) return MQ_ERR_ARG;
+  if (npass == 0 || count == 0) return MQ_OK;
+  const int64_t n = rows * cols;
+  if (n == 0) return MQ_ERR_ARG;
+  const int32_t chunks = (count + MQ_MAX_BATCH - 1) / MQ_MAX_BATCH;
+  if ((int64_t)npass * chunks > MQ_P99_MAX_UNITS) return MQ_ERR_UNSUPPORTED;
+  for (int32_t k = 0; k < npass; ++k) {
+    const mq_p99_pass& ps = passes[k];
+    if (!ps.items || !ps.cfg || !ps.p99) return MQ_ERR_ARG;
+    const mq_quant_cfg* cfg = ps.cfg;
+    const bool is_lut = cfg->format == MQ_LUT_FP || cfg->format == MQ_LUT_FP_SUB;
+    if (cfg->format != MQ_INT_SYM && cfg->format != MQ_INT_ASYM && !is_lut) return MQ_ERR_ARG;
+    if (!is_lut && (cfg->bits < 2 || cfg->bits > 8)) return MQ_ERR_UNSUPPORTED;
+    if (cfg->f32_math && !(is_lut && cfg->group_size == -1)) return MQ_ERR_UNSUPPORTED;
+    if (cfg->group_size > 0 && cols % cfg->group_size != 0) return MQ_ERR_GROUP;
+    for (int32_t i = 0; i < count; ++i) {
+      const mq_quant_out& o = ps.items[i].out;
+      if (!ps.items[i].w || !o.abs_err || o.abs_err_dtype != MQ_F32) return MQ_ERR_ARG;
+      if (!aligned(o.abs_err, 16)) return MQ_ERR_ALIGN;
+      // the list percentile reads the float32 per-segment mean squared errors the pass writes
+      if (ps.list_p99 && !(o.seg_sse && o.seg_mse_f32 == 1 && aligned(o.seg_sse, 16))) return MQ_ERR_ARG;
+    }
+  }
+  if (!workspace || workspace_bytes < mq_quantize_p99_passes_workspace_bytes(npass, count, rows, cols)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 256)) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  std::lock_guard<std::mutex> lock(g_pass_mu);
+  int rc = MQ_OK;
+  PassStreams* S = pass_streams(&rc);
+  if (!S) return rc;
+  const int32_t cmax = count < MQ_MAX_BATCH ? count : MQ_MAX_BATCH;
+  const int total_units = npass * chunks;
+  const int64_t sstride = sample_stride_elems(n);
+  // workspace: per unit the launch's reduction slices | per unit the selection slices | per unit the samples
+  const size_t red_bytes = sel_slices_offset(cmax), slice_bytes = (size_t)cmax * sel_ws_bytes();
+  char* const red0 = static_cast<char*>(workspace);
+  char* const sel0 = red0 + (size_t)total_units * red_bytes;
+  char* const smp0 = sel0 + (size_t)total_units * slice_bytes;
+  struct Unit { const mq_quant_item* it; const mq_quant_cfg* cfg; int32_t c; float* p99; double* lp; char* ws; char* sel;
+                uint16_t* samples; bool fed; int64_t m; };
+  Unit units[MQ_P99_MAX_UNITS];
+  int nu = 0;
+  for (int32_t k = 0; k < npass; ++k)
+    for (int32_t done = 0; done < count; done += MQ_MAX_BATCH) {
+      Unit& u = units[nu];
+      u.c = count - done < MQ_MAX_BATCH ? count - done : MQ_MAX_BATCH;
+      u.it = passes[k].items + done;
+      u.cfg = passes[k].cfg;
+      u.p99 = passes[k].p99 + done;
+      u.lp = passes[k].list_p99 ? passes[k].list_p99 + done : nullptr;
+      u.ws = red0 + (size_t)nu * red_bytes;
+      u.sel = sel0 + (size_t)nu * slice_bytes;
+      u.samples = reinterpret_cast<uint16_t*>(smp0 + (size_t)nu * (size_t)cmax * (size_t)sstride * 2);
+      u.m = 0;
+      if ((rc = quantize_launch(u.it, u.c, w_dtype, rows, cols, u.cfg, u.ws, st, SEL_FEED_OFF, nullptr, &u.m))) return rc;
+      u.fed = u.m > 0 && sel_feed_eligible(n, u.m, pct);
+      ++nu;
+    }
+  // Units [i0, i1) share the launches that are per selection slice when their slices (and samples) follow each other
+  // in the workspace -- one chunk per pass -- and, where results are written, so do the caller's result arrays; at
+  // most SEL_MAX_BATCH slices per launch.
+  auto group_end = [&](int i0, bool same_m, bool outputs) {
+    int i1 = i0 + 1, tot = units[i0].c;
+    while (i1 < nu && chunks == 1 && tot + units[i1].c <= SEL_MAX_BATCH) {
+      const Unit &a = units[i1 - 1], &c = units[i1];
+      if (a.fed != c.fed || (same_m && a.m != c.m)) break;
+      if (outputs && !(c.p99 == a.p99 + a.c && (a.lp != nullptr) == (c.lp != nullptr) && (!a.lp || c.lp == a.lp + a.c))) break;
+      tot += c.c;
+      ++i1;
+    }
+    return i1;
+  };
+  // From the first launch on the second stream a failure leaves work enqueued there; the caller's stream is joined
+  // to it before returning either way.
+  auto join = [&]() {
+    (void)hipEventRecord(S->done, S->post);
+    (void)hipStreamWaitEvent(st, S->done, 0);
+  };
+  // 1. the front chains, on the caller's stream
+  for (int i0 = 0; i0 < nu;) {
+    const int i1 = group_end(i0, true, false);
+    if (units[i0].fed) {
+      int tot = 0;
+      for (int i = i0; i < i1; ++i) tot += units[i].c;
+      if ((rc = sel_feed_begin(units[i0].sel, tot, st))) return rc;
+      for (int i = i0; i < i1; ++i) {
+        const Unit& u = units[i];
+        if ((rc = quantize_launch(u.it, u.c, w_dtype, rows, cols, u.cfg, u.ws, st, SEL_FEED_SAMPLE, u.sel, nullptr, u.samples,
+                                  sstride)))
+          return rc;
+      }
+      if ((rc = sel_feed_bracket(units[i0].sel, tot, units[i0].samples, sstride, n, units[i0].m, pct, st))) return rc;
+    }
+    i0 = i1;
+  }
+  // 2. the full passes back to back; behind each, on the second stream: its partial sums, bracket scan, candidates
+  for (int i = 0; i < nu && !rc; ++i) {
+    const Unit& u = units[i];
+    tl_totals_stream = S->post;
+    tl_totals_event = S->main_ev[i];  // (recorded behind the quantize kernel; the second stream waits for it)
+    rc = u.fed ? quantize_launch(u.it, u.c, w_dtype, rows, cols, u.cfg, u.ws, st, SEL_FEED_COUNT, u.sel)
+               : quantize_launch(u.it, u.c, w_dtype, rows, cols, u.cfg, u.ws, st);
+    tl_totals_stream = nullptr;
+    tl_totals_event = nullptr;
+    if (!rc && u.fed) {
+      const void* errs[MQ_MAX_BATCH];
+      for (int j = 0; j < u.c; ++j) errs[j] = u.it[j].out.abs_err;
+      rc = sel_feed_finish(u.sel, u.c, errs, n, pct, u.p99, S->post, SEL_FINISH_BRACKET);
+    }
+  }
+  // 3. behind the last full pass: the guarded exact route of the fed units, the selections from the stored arrays,
+  //    the list percentiles
+  for (int i0 = 0; i0 < nu && !rc;) {
+    const int i1 = group_end(i0, false, true);
+    const void* xs[SEL_MAX_BATCH];
+    int64_t ns[SEL_MAX_BATCH];
+    int tot = 0;
+    for (int i = i0; i < i1; ++i)
+      for (int j = 0; j < units[i].c; ++j) { xs[tot] = units[i].it[j].out.abs_err; ns[tot] = n; ++tot; }
+    const Unit& u = units[i0];
+    rc = u.fed ? sel_feed_finish(u.sel, tot, xs, n, pct, u.p99, S->post, SEL_FINISH_EXACT)
+               : mq_percentile_multi(xs, ns, tot, MQ_F32, pct, u.p99, nullptr, u.sel, (size_t)tot * sel_ws_bytes(), S->post);
+    if (!rc && u.lp) {
+      tot = 0;
+      for (int i = i0; i < i1; ++i) {
+        const int64_t gs = units[i].cfg->group_size;
+        const int64_t L = gs == -1 ? n : (gs <= 0 ? cols : gs);
+        for (int j = 0; j < units[i].c; ++j) { xs[tot] = units[i].it[j].out.seg_sse; ns[tot] = n / L; ++tot; }
+      }
+      rc = mq_percentile_multi(xs, ns, tot, MQ_F32_AS_F64, list_pct, u.lp, nullptr, u.sel, (size_t)tot * sel_ws_bytes(), S->post);
+    }
+    i0 = i1;
+  }
+  join();
+  if (rc) return rc;
+  MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
 #endif  // MQ_PART == 0

@@ -77,7 +77,12 @@ bool sel_feed_eligible(int64_t n, int64_t m, double pct);
 int sel_feed_begin(void* ws, int count, hipStream_t st);
 int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sample_stride, int64_t n, int64_t m,
                      double pct, hipStream_t st);
-int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st);
+// part: everything, only the bracket's own resolution (scan + kept candidates), or only the guarded exact route --
+// the two halves may be enqueued at different places (the exact route's kernels are large workgroups that do not fit
+// beside a running full pass; each returns at once for a slice the bracket resolved)
+enum { SEL_FINISH_ALL = 0, SEL_FINISH_BRACKET = 1, SEL_FINISH_EXACT = 2 };
+int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st,
+                    int part = SEL_FINISH_ALL);
 
 // ---- percentile of a per-vector MSE list selected inside the statistics pass (sweep launches) -----------------
 // The list of a large tensor is not written: a sampling launch evaluates one wave step of every `unit` steps and

@@ -31,6 +31,8 @@
 //            otherwise the slice's `ok` flag stays 0 and the exact level-0/level-1 kernels, which are
 //            always enqueued behind and return at once when `ok` is set, produce the result.
 // The bracket is only ever a guess about where to look: the counts that decide are exact.
+#include <mutex>
+
 #include "mq_sel.h"
 
 struct SelBatch {
@@ -556,27 +558,96 @@ __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
   flush_top(lh, ws->samp, ws->samp_coarse);
 }
 
-// Level-0 histogram of the samples a feeding kernel stored (top 16 bits of each value, m per array).
-__global__ __launch_bounds__(1024) void k_sel_sample_u16(const SelBatch b, const uint16_t* samples, int64_t stride,
-                                                         int64_t m) {
-  extern __shared__ uint32_t lh[];
+// Level-0 histogram of the samples a feeding kernel stored (top 16 bits of each value, m per array), 256 threads and
+// 9 KiB of LDS per workgroup: a window of 2048 consecutive counters, placed so that the largest of the workgroup's
+// first samples sits at least 256 counters under its top (the samples of an error array thin out by half per 128
+// counters below the largest ones), plus the counters 0 .. 255 (an error that is exactly zero is common, and one
+// global counter taking every workgroup's zeros serialises them in one L2 channel: 0.3 ms).  A sample outside both
+// goes to the global counters directly: rare, and spread over many addresses.  (A workgroup-wide histogram of all
+// 32768 counters -- 128 KiB, one workgroup per CU, every one of them clearing and flushing the lot -- took 55 us for
+// 48 arrays of 512 Ki samples.)
+#define SEL_SAMPLE_WINDOW 2048
+__global__ __launch_bounds__(256) void k_sel_sample_u16_window(const SelBatch b, const uint16_t* samples, int64_t stride,
+                                                                int64_t m) {
+  __shared__ uint32_t lh[SEL_SAMPLE_WINDOW + 256];  // the window, then the counters 0 .. 255
+  __shared__ uint32_t wmax[4];
   const uint16_t* x = samples + (int64_t)blockIdx.y * stride;
   SelWs* ws = batch_ws(b, blockIdx.y);
-  for (int i = threadIdx.x; i < SEL_TOP_BINS; i += blockDim.x) lh[i] = 0;
-  __syncthreads();
+  uint32_t* fine = ws->samp;
+  uint32_t* coarse = ws->samp_coarse;
   const int64_t nvec = m / 8;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t v = t0; v < nvec; v += step) {
-    u32x4 raw = reinterpret_cast<const u32x4*>(x)[v];
+  for (int i = threadIdx.x; i < SEL_SAMPLE_WINDOW + 256; i += blockDim.x) lh[i] = 0;
+  // the window, from the workgroup's first vectors
+  uint32_t mx = 0;
+  if (t0 < nvec) {
+    const u32x4 raw = reinterpret_cast<const u32x4*>(x)[t0];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      atomicAdd(&lh[raw[k] & 0x7fffu], 1u);
-      atomicAdd(&lh[(raw[k] >> 16) & 0x7fffu], 1u);
+      const uint32_t lo = raw[k] & 0x7fffu, hi = (raw[k] >> 16) & 0x7fffu;
+      mx = mx > lo ? mx : lo;
+      mx = mx > hi ? mx : hi;
     }
   }
-  for (int64_t i = nvec * 8 + t0; i < m; i += step) atomicAdd(&lh[x[i] & 0x7fffu], 1u);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o; }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
   __syncthreads();
-  flush_top(lh, ws->samp, ws->samp_coarse);
+  mx = wmax[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) mx = mx > wmax[w] ? mx : wmax[w];
+  // base: a multiple of 256 (a wave's 64 consecutive counters then share one coarse counter in the flush)
+  uint32_t top = ((mx + 256u) | 255u) + 1u;
+  top = top > (uint32_t)SEL_TOP_BINS ? (uint32_t)SEL_TOP_BINS : top;
+  const uint32_t base = top > (uint32_t)SEL_SAMPLE_WINDOW ? top - (uint32_t)SEL_SAMPLE_WINDOW : 0u;
+  auto put = [&](uint32_t bin) {
+    const uint32_t rel = bin - base;
+    if (rel < (uint32_t)SEL_SAMPLE_WINDOW) {
+      atomicAdd(&lh[rel], 1u);
+    } else if (bin < 256u) {
+      atomicAdd(&lh[SEL_SAMPLE_WINDOW + bin], 1u);
+    } else {
+      atomicAdd(&fine[bin], 1u);
+      atomicAdd(&coarse[bin >> 8], 1u);
+    }
+  };
+  constexpr int U = 4;  // loads in flight per thread
+  for (int64_t v0 = t0; v0 < nvec; v0 += U * step) {
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * step;
+      raw[u] = v < nvec ? reinterpret_cast<const u32x4*>(x)[v] : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v0 + u * step >= nvec) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        put(raw[u][k] & 0x7fffu);
+        put((raw[u][k] >> 16) & 0x7fffu);
+      }
+    }
+  }
+  for (int64_t i = nvec * 8 + t0; i < m; i += step) put(x[i] & 0x7fffu);
+  __syncthreads();
+  for (int i = threadIdx.x; i < SEL_SAMPLE_WINDOW; i += blockDim.x) {
+    const uint32_t c = lh[i];
+    if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;
+    if (c) atomicAdd(&fine[base + i], c);
+    uint32_t sum = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&coarse[(base + i) >> 8], sum);
+  }
+  if (base >= 256u) {  // (otherwise the window holds those counters itself)
+    const uint32_t c = lh[SEL_SAMPLE_WINDOW + threadIdx.x];
+    if (c) atomicAdd(&fine[threadIdx.x], c);
+    uint32_t sum = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&coarse[0], sum);
+  }
 }
 
 // Bins of the two sample ranks -> bracket.
@@ -750,8 +821,12 @@ __global__ __launch_bounds__(256) void k_sel_scan_bracket(const SelBatch b, cons
 // the bracket, are resolved among the list in two sweeps of 12 bits over the patterns' offsets from the bracket's
 // first pattern (the list is a few hundred KiB and stays in L2).  Slices with a narrow bracket, a missed bracket or an overflowed list are left alone (the
 // exact route over the stored array, enqueued behind, handles whatever has ok == 0).
-__global__ __launch_bounds__(1024) void k_sel_cand(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+// (256 threads: beside a full quantize pass of another configuration, which keeps every CU's wave slots taken, a
+//  1024-thread workgroup waits for sixteen free slots on one CU until that pass drains -- measured 370 us against 5)
+#define SEL_CAND_THREADS 256
+__global__ __launch_bounds__(SEL_CAND_THREADS) void k_sel_cand(const SelBatch b, const SelRanks rk, FinishArgs fin) {
   constexpr int BITS = 12, NB = 1 << BITS;  // keys relative to the bracket's first pattern: < 2^24, two sweeps
+  constexpr int BPT = NB / SEL_CAND_THREADS;  // consecutive bins a thread owns in the scan
   __shared__ uint32_t hist[2][NB];
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t s_prefix[2];
@@ -801,13 +876,13 @@ __global__ __launch_bounds__(1024) void k_sel_cand(const SelBatch b, const SelRa
     }
     for (uint64_t i = nvec * 4 + threadIdx.x; i < n; i += blockDim.x) put(x[i]);
     __syncthreads();
-    for (int r = 0; r < 2; ++r) {  // every thread owns four consecutive bins
+    for (int r = 0; r < 2; ++r) {  // every thread owns BPT consecutive bins
       const uint32_t* h = hist[(same || r == 0) ? 0 : 1];
       const uint64_t want = s_rank[r];
-      uint32_t c[4];
+      uint32_t c[BPT];
+      uint32_t mine = 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = h[4 * threadIdx.x + j];
-      const uint32_t mine = (c[0] + c[1]) + (c[2] + c[3]);
+      for (int j = 0; j < BPT; ++j) { c[j] = h[BPT * threadIdx.x + j]; mine += c[j]; }
       uint32_t inc = mine;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -822,7 +897,7 @@ __global__ __launch_bounds__(1024) void k_sel_cand(const SelBatch b, const SelRa
       if (want >= before && want < before + mine) {
         int j = 0;
         while (want >= before + c[j]) { before += c[j]; ++j; }
-        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint32_t)(4 * threadIdx.x + j) << shift);
+        s_prefix[r] = (r == 0 ? p0 : p1) | ((uint32_t)(BPT * threadIdx.x + j) << shift);
         s_rank[r] = want - before;
       }
       __syncthreads();
@@ -1250,12 +1325,13 @@ int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sampl
     sr.lo[i] = (uint64_t)lo;
     sr.hi[i] = (uint64_t)hi;
   }
-  int64_t nb = (m / 8 + 1024 * 4 - 1) / (1024 * 4);
-  int64_t cap = 256 / count < 2 ? 2 : 256 / count;
-  MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample_u16), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             SEL_TOP_BINS * 4));
-  hipLaunchKernelGGL(k_sel_sample_u16, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count), dim3(1024),
-                     SEL_TOP_BINS * 4, st, b, samples, sample_stride, m);
+  // (each workgroup's flush is ~1500 global atomics into the array's counters, and the chip takes about 120 of them
+  //  per microsecond: 48 arrays x 512 Ki samples took 26 / 22 / 28 / 38 us with 10 / 16 / 24 / 42 workgroups per
+  //  array, 11 us of it the loads -- scratch/sample_hist_probe.hip)
+  int64_t nb = (m / 8 + 256 * 16 - 1) / (256 * 16);
+  const int64_t cap = 768 / count < 4 ? 4 : 768 / count;
+  hipLaunchKernelGGL(k_sel_sample_u16_window, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count), dim3(256),
+                     0, st, b, samples, sample_stride, m);
   hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)count), dim3(256), 0, st, b, sr);
   hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / count < 8 ? 8 : 512 / count), (unsigned)count), dim3(256),
                      0, st, b);
@@ -1263,7 +1339,8 @@ int sel_feed_bracket(void* ws, int count, const uint16_t* samples, int64_t sampl
   return MQ_OK;
 }
 
-int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st) {
+int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, double pct, void* out, hipStream_t st,
+                    int part) {
   SelBatch b;
   feed_batch(ws, count, xs, n, &b);
   SelRanks rk = {};
@@ -1275,9 +1352,12 @@ int sel_feed_finish(void* ws, int count, const void* const* xs, int64_t n, doubl
     rk.k1[i] = (uint64_t)k1;
   }
   FinishArgs fin_last = {MQ_F32, static_cast<char*>(out), nullptr};
-  hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)count), dim3(256), 0, st, b, rk, fin_last, 1);
-  hipLaunchKernelGGL(k_sel_cand, dim3((unsigned)count), dim3(1024), 0, st, b, rk, fin_last);
-  MQ_HIP(hipGetLastError());
+  if (part != SEL_FINISH_EXACT) {
+    hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)count), dim3(256), 0, st, b, rk, fin_last, 1);
+    hipLaunchKernelGGL(k_sel_cand, dim3((unsigned)count), dim3(SEL_CAND_THREADS), 0, st, b, rk, fin_last);
+    MQ_HIP(hipGetLastError());
+  }
+  if (part == SEL_FINISH_BRACKET) return MQ_OK;
   for (int level = 0; level <= 1; ++level) {  // the exact route, skipped per slice when the bracket held
     int rc = launch_accumulate(b, count, n, MQ_F32, level, st, 1);
     if (rc) return rc;

@@ -88,6 +88,7 @@ class QuantResult:
     seg_mse: Optional[torch.Tensor] = None  # float32 [nseg]: float32(sum / segment length), instead of seg_sse
     totals: Optional[torch.Tensor] = None   # float64 [2]: sum err^2, sum |err|
     abs_p99: Optional[torch.Tensor] = None  # float32 [B]: percentile of the float32 |error| (quantize_batch(p99=))
+    list_p99: Optional[torch.Tensor] = None  # float64 [B]: percentile of the seg_mse list (quantize_batch_passes)
 
 
 def require_device(t: torch.Tensor) -> torch.Tensor:
@@ -224,6 +225,10 @@ def bind_batch():
                                              ctypes.c_int64, ctypes.POINTER(_lib.QuantCfg), ctypes.c_double,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
         i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+        L_.mq_quantize_p99_passes_workspace_bytes.restype = sz
+        L_.mq_quantize_p99_passes_workspace_bytes.argtypes = [i32, i32, i64, i64]
+        L_.mq_quantize_p99_passes.restype = ctypes.c_int
+        L_.mq_quantize_p99_passes.argtypes = [vp, i32, i32, i32, i64, i64, ctypes.c_double, ctypes.c_double, vp, sz, vp]
         L_.mq_sweep_table_bytes.restype = sz
         L_.mq_sweep_table_bytes.argtypes = [i32]
         L_.mq_sweep_workspace_bytes.restype = sz
@@ -284,6 +289,118 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
 
     p99: a percentile (e.g. 99) of each tensor's float32 |error| array, selected exactly while the errors
     are produced (result.abs_p99, float32 [B]); needs abs_err=torch.float32."""
+    res, items, cfg, (B, rows, cols, w0) = _batch_setup(w, fmt, bits, group_size, datatype, f32_math, deq, codes, scale,
+                                                         abs_err, seg_sse, seg_mse, totals, p99, out)
+    if items is None:
+        return res
+    dev = w0.device
+    L_ = bind_batch()
+    with torch.cuda.device(dev):
+        if p99 is not None:
+            ws, stream = workspace(dev, L_.mq_quantize_p99_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
+            st = L_.mq_quantize_p99_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), float(p99),
+                                          res.abs_p99.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
+        else:
+            ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
+            st = L_.mq_quantize_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
+                                      ws.numel(), stream.cuda_stream)
+    _lib.check(st)
+    return res
+
+
+class _P99Pass(ctypes.Structure):
+    _fields_ = [("items", ctypes.POINTER(_QuantItem)), ("cfg", ctypes.POINTER(_lib.QuantCfg)), ("p99", ctypes.c_void_p),
+                ("list_p99", ctypes.c_void_p)]
+
+
+@torch.no_grad()
+def quantize_batch_passes(w, passes, p99: float = 99.0, list_p99: Optional[float] = None,
+                          out: Optional[list] = None) -> list:
+    """Several quantize_batch(..., p99=p99) passes over ONE stack of same-shaped weights -- the configurations of a
+    sweep (mq_quantize_p99_passes): the same results as the separate calls, with the short selection kernels of each
+    pass running beside the neighbouring full passes.
+
+    passes: a list of dicts of quantize_batch's arguments (fmt, bits, group_size, datatype, deq, codes, scale, seg_mse,
+    totals ...; abs_err is float32 in every pass).  list_p99: also the percentile of each tensor's per-segment MSE list
+    (float64, np.percentile of the list as float64; every pass must then ask for seg_mse=True) -> result.list_p99.
+    out: the list a previous call returned, to reuse its buffers.  -> one QuantResult per pass."""
+    if not passes:
+        return []
+    if out is not None and len(out) != len(passes):
+        raise ValueError("quantize_batch_passes(): `out` must hold one result per pass")
+    # the same call again on the results of the last one: the item tables built then are still right
+    key = ((w.data_ptr(), tuple(w.shape), w.dtype) if isinstance(w, torch.Tensor) else
+           tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in w),
+           tuple(tuple(sorted((a, str(b)) for a, b in ps.items())) for ps in passes), p99, list_p99)
+    cached = getattr(out[0], "_passes_call", None) if out else None
+    if cached is not None and cached[0] == key:
+        _, arr, npass, B, dt, rows, cols, dev, keep = cached
+        L_ = bind_batch()
+        with torch.cuda.device(dev):
+            ws, stream = workspace(dev, L_.mq_quantize_p99_passes_workspace_bytes(npass, B, rows, cols))
+            st = L_.mq_quantize_p99_passes(arr, npass, B, dt, rows, cols, float(p99),
+                                           float(list_p99 if list_p99 is not None else 50.0), ws.data_ptr(), ws.numel(),
+                                           stream.cuda_stream)
+        _lib.check(st)
+        return out
+    setups = []
+    for k, ps in enumerate(passes):
+        kw = dict(bits=8, group_size=None, datatype=None, f32_math=False, deq=True, codes=True, scale=True,
+                  seg_sse=False, seg_mse=False, totals=False)
+        kw.update(ps)
+        if kw.pop("abs_err", torch.float32) != torch.float32:
+            raise ValueError("quantize_batch_passes(): the |error| percentile needs the float32 abs_err output")
+        if list_p99 is not None and kw["seg_mse"] is not True:
+            raise ValueError("quantize_batch_passes(): list_p99 needs seg_mse=True in every pass")
+        setups.append(_batch_setup(w, kw["fmt"], kw["bits"], kw["group_size"], kw["datatype"], kw["f32_math"], kw["deq"],
+                                   kw["codes"], kw["scale"], torch.float32, kw["seg_sse"], kw["seg_mse"], kw["totals"],
+                                   p99, None if out is None else out[k]))
+    results = [s[0] for s in setups]
+    _, items0, _, (B, rows, cols, w0) = setups[0]
+    if items0 is None:
+        return results
+    dev = w0.device
+    arr = (_P99Pass * len(setups))()
+    # the passes' percentile arrays follow each other in memory (the library then takes them in one set of launches)
+    all_p99 = torch.empty(len(setups), B, dtype=torch.float32, device=dev)
+    all_lp = torch.empty(len(setups), B, dtype=torch.float64, device=dev) if list_p99 is not None else None
+    for k, (res, items, cfg, _) in enumerate(setups):
+        bufs = res._bufs
+        res.abs_p99 = bufs["abs_p99"] = all_p99[k]
+        bufs.pop("list_p99", None)
+        lp = None
+        if all_lp is not None:
+            lp = bufs["list_p99"] = all_lp[k]
+        res.list_p99 = lp
+        res._keep = (items, cfg)
+        arr[k].items = items
+        arr[k].cfg = ctypes.pointer(cfg)
+        arr[k].p99 = res.abs_p99.data_ptr()
+        arr[k].list_p99 = None if lp is None else lp.data_ptr()
+    L_ = bind_batch()
+    with torch.cuda.device(dev):
+        ws, stream = workspace(dev, L_.mq_quantize_p99_passes_workspace_bytes(len(setups), B, rows, cols))
+        st = L_.mq_quantize_p99_passes(arr, len(setups), B, _DTYPES[w0.dtype], rows, cols, float(p99),
+                                       float(list_p99 if list_p99 is not None else 50.0), ws.data_ptr(), ws.numel(),
+                                       stream.cuda_stream)
+    _lib.check(st)
+    # (kept with the results: the tables, and the weights whose addresses they hold)
+    results[0]._passes_call = (key, arr, len(setups), B, _DTYPES[w0.dtype], rows, cols, dev, (w, [s[1:3] for s in setups]))
+    return results
+
+
+def passes_percentiles(results):
+    """The percentile arrays of quantize_batch_passes' results as the two buffers they are slices of:
+    (abs_p99 float32 [passes * B], list_p99 float64 [passes * B] or None), pass after pass."""
+    a = results[0].abs_p99._base
+    lp = results[0].list_p99
+    return a.view(-1), (None if lp is None else lp._base.view(-1))
+
+
+def _batch_setup(w, fmt, bits, group_size, datatype, f32_math, deq, codes, scale, abs_err, seg_sse, seg_mse, totals, p99,
+                 out):
+    """The argument checks, output buffers and item table of a quantize_batch call.
+    -> (result, items or None when there is nothing to launch, cfg, (B, rows, cols, first tensor))"""
     if p99 is not None and abs_err != torch.float32:
         raise ValueError("p99 needs the float32 abs_err output")
     if seg_sse and seg_mse:
@@ -353,7 +470,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
     if n == 0 or B == 0:
         if res.totals is not None:
             res.totals.zero_()
-        return res
+        return res, None, cfg, (B, rows, cols, w0)
 
     def span(t):  # (address of slice 0, bytes between slices)
         return (None, 0) if t is None else (t.data_ptr(), t.stride(0) * t.element_size())
@@ -383,18 +500,7 @@ def quantize_batch(w: torch.Tensor, fmt: int, bits: int = 8, group_size=None, da
             o.seg_sse = p_seg + i * s_seg
         if p_tot is not None:
             o.totals = p_tot + i * s_tot
-    L_ = bind_batch()
-    with torch.cuda.device(dev):
-        if p99 is not None:
-            ws, stream = workspace(dev, L_.mq_quantize_p99_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
-            st = L_.mq_quantize_p99_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), float(p99),
-                                          res.abs_p99.data_ptr(), ws.data_ptr(), ws.numel(), stream.cuda_stream)
-        else:
-            ws, stream = workspace(dev, L_.mq_quantize_batch_workspace_bytes(B, rows, cols, ctypes.byref(cfg)))
-            st = L_.mq_quantize_batch(items, B, _DTYPES[w0.dtype], rows, cols, ctypes.byref(cfg), ws.data_ptr(),
-                                      ws.numel(), stream.cuda_stream)
-    _lib.check(st)
-    return res
+    return res, items, cfg, (B, rows, cols, w0)
 
 
 @torch.no_grad()

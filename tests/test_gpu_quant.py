@@ -680,3 +680,43 @@ def test_zero_point_sign_of_zero_numpy_order_launch(oracle, dt):
         assert (exp["zp"] == 0x8000).sum() > 10 and (exp["zp"] == 0).sum() > 10
         assert np.array_equal(_bits16(zp), exp["zp"]), int((_bits16(zp) != exp["zp"]).sum())
         assert np.array_equal(_bits16(sc), exp["scale"])
+
+
+def test_passes_enqueued_together_equal_separate_calls():
+    """quantize_batch_passes (mq_quantize_p99_passes: the passes of a sweep enqueued together, their selection chains
+    on the library's two streams beside the neighbouring full passes) against one quantize_batch(p99=) call per pass
+    plus percentile_rows over its lists: every output bit for bit.  Shapes on the fed route (groups of a large
+    tensor), on the fallback (small tensors, per-channel rows: selection from the stored errors) and a stack of more
+    than 32 tensors (two chunks per pass); twice, the second time reusing the results' buffers."""
+    from quantization_amd import _lib
+    from quantization_amd.error_metrics import percentile_rows
+    from quantization_amd.fused import quantize_batch, quantize_batch_passes
+    g = torch.Generator().manual_seed(41)
+    outs = dict(deq=True, codes=True, scale=True, seg_mse=True, totals=True)
+    cases = [((6, 1024, 2048), [(_lib.INT_ASYM, 8, 32, None), (_lib.INT_ASYM, 8, 64, None), (_lib.INT_ASYM, 8, 128, None),
+                                (_lib.LUT_FP, 8, 64, "fp8_e4m3"), (_lib.INT_SYM, 4, None, None)]),
+             ((3, 64, 256), [(_lib.INT_ASYM, 8, 32, None), (_lib.INT_SYM, 8, None, None), (_lib.INT_SYM, 8, -1, None)]),
+             ((40, 128, 512), [(_lib.INT_SYM, 8, 32, None), (_lib.LUT_FP, 4, 128, "fp4")])]
+    for shape, passes in cases:
+        w = (torch.randn(*shape, generator=g) * 0.02).half().cuda()
+        want = []
+        for fmt, bits, gs, dt in passes:
+            r = quantize_batch(w, fmt, bits, gs, dt, abs_err=torch.float32, p99=99, **outs)
+            lp = percentile_rows([r.seg_mse], 97, wide=True)
+            want.append((r, lp))
+        torch.cuda.synchronize()
+        got = None
+        for rep in range(2):
+            got = quantize_batch_passes(w, [dict(fmt=f, bits=b, group_size=gs, datatype=dt, **outs) for f, b, gs, dt in passes],
+                                        p99=99, list_p99=97, out=got)
+            torch.cuda.synchronize()
+            for (r, lp), q, ps in zip(want, got, passes):
+                for name in ("deq", "codes", "scale", "zero_point", "abs_err", "seg_mse", "totals", "abs_p99"):
+                    a, b = getattr(r, name), getattr(q, name)
+                    assert (a is None) == (b is None), (shape, ps, name)
+                    if a is not None:
+                        assert torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a,
+                                           b.view(torch.uint8) if b.dtype != torch.uint8 else b), (shape, ps, name, rep)
+                assert torch.equal(lp.view(torch.int64), q.list_p99.view(torch.int64)), (shape, ps, "list_p99", rep)
+    with pytest.raises(ValueError):
+        quantize_batch_passes(w, [dict(fmt=_lib.INT_SYM, seg_mse=False)], list_p99=99)
