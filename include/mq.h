@@ -318,6 +318,32 @@ int mq_sweep_records(const double* totals, const double* p99, const double* nume
                      double* records, void* hip_stream);
 
 /*
+ * Several groupings of ONE format from one read of the weights: the reference's sweeps quantize the same tensor once
+ * per (format, grouping) -- per row, groups of 32 / 64 / 128 (MSE&P99/quant_error_single_weight.py:56-71 per
+ * configuration file; the configurations of onnx_error_cli.py) -- and this launch computes up to four of them while a
+ * row is in registers.  Per tensor and grouping slot c (0: rows, 1: groups of 32, 2: 64, 3: 128; `mask` bit c set):
+ * list[c], the float32 per-segment mean squared errors (rows x cols / L entries, as seg_sse with seg_mse_f32 = 1),
+ * and totals[c] = (sum err^2, sum |err|) in float64 -- the outputs of mq_sweep_run for that grouping, to its
+ * tolerance (the sums are taken in another order; scales, codes and errors are the same arithmetic).  Statistics
+ * only.  All tensors of a launch have `cols` columns (a multiple of 128, at most 32768), float16 / bfloat16, 16-byte
+ * aligned; cfg->group_size is ignored.  prepare fills the HOST table (mq_sweep_multi_table_bytes(count) bytes) that
+ * the caller copies to the device; run launches over the device copy (workspace:
+ * mq_sweep_multi_workspace_bytes(total_blocks), 16-byte aligned).
+ */
+typedef struct mq_multi_item {
+  const void* w;
+  void* list[4];     /* float32 lists per slot (NULL where the mask bit is clear) */
+  double* totals[4]; /* two doubles per slot */
+} mq_multi_item;
+size_t mq_sweep_multi_table_bytes(int32_t count);
+size_t mq_sweep_multi_workspace_bytes(int64_t total_blocks);
+int mq_sweep_multi_prepare(const mq_multi_item* items, const int64_t* rows, int64_t cols, int32_t count, int32_t w_dtype,
+                           const mq_quant_cfg* cfg, uint32_t mask, void* table_host, size_t table_bytes,
+                           int64_t* total_blocks);
+int mq_sweep_multi_run(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
+                       const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/*
  * mq_quantize_batch plus p99[i] = np.percentile(abs_err_i, pct) (float32, method 'linear': the P99 of
  * elwise_error/onnx_error_cli.py:113-114) for every tensor, with the selection fed from the quantize pass
  * itself: a sampling pass over 1/32 of the weight brackets the wanted ranks, the full pass counts the errors

@@ -161,6 +161,9 @@ struct QuantBatch {
   NumpyProg np;        // SC_STATS_ROWNP only
   const SweepItem* sweep;  // non-null: a sweep launch (sweep_count entries sorted by blk0); item[] is unused
   const struct NpRowProg* rowprog;  // numpy-order row kernels: the row's summation program (device memory)
+  const struct MultiItem* multi;    // k_stats_multi: the launch's tensors (device memory, sorted by blk0) ...
+  int32_t multi_count;              // ... how many, and which groupings are computed (bit 0 rows, 1 .. 3: groups of
+  uint32_t multi_mask;              //     32 / 64 / 128); sweep_partials holds 8 doubles per workgroup then
   int32_t sweep_count;
   double* sweep_partials;  // [total workgroups][2]
   int64_t ws_stride;   // bytes between the tensors' workspace slices
@@ -1823,6 +1826,7 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) ? 3 : NV <= 4 ? 6 : 4)) void k
 }
 
 #include "mq_np.h"
+#include "mq_multi.h"
 
 // Runs a post-order program of numpy's split tree (see NumpyProg) over the leaves' sums: bit 0 takes the next leaf's
 // sum, bit 1 adds the two newest partial sums (the older one on the left).  One lane; the stack lives in registers
@@ -2460,7 +2464,7 @@ static bool recip_ok_cached(float c) {
 
 #endif  // MQ_PART == 0
 
-#if MQ_PART >= 1 && !defined(MQ_NP_UNIT)
+#if MQ_PART >= 1 && !defined(MQ_NP_UNIT) && !defined(MQ_MULTI_UNIT)
 template <int FMT, int NV, int SEL>
 static void launch_team(int team_log2, dim3 grid, size_t lds, hipStream_t st, const QuantBatch& p) {
   static_assert(SEL_FEED_THREADS == 256, "the feeding kernels' candidate stages assume four waves per workgroup");
@@ -2580,8 +2584,41 @@ int MQ_CAT(mq_launch_np, MQ_PART)(int bf16, int scope, int nv, int team_log2, di
 }
 #endif
 
+// The several-groupings kernels of one format (their own translation units: MQ_MULTI_UNIT).
+#if MQ_PART >= 1 && defined(MQ_MULTI_UNIT)
+#define MQ_CAT2(a, b) a##b
+#define MQ_CAT(a, b) MQ_CAT2(a, b)
+template <int FMT, bool BF16>
+static int launch_multi(int nr, int wpr, dim3 grid, hipStream_t st, const QuantBatch& b) {
+#define MQ_MULTI(NR, WPR) hipLaunchKernelGGL((k_stats_multi<FMT, BF16, NR, WPR>), grid, dim3(256), 0, st, b)
+  if (wpr == 1) {
+    switch (nr) {
+      case 1: MQ_MULTI(1, 1); break;
+      case 2: MQ_MULTI(2, 1); break;
+      case 3: MQ_MULTI(3, 1); break;
+      case 4: MQ_MULTI(4, 1); break;
+      default: return MQ_ERR_UNSUPPORTED;
+    }
+  } else {
+    switch (nr) {
+      case 1: MQ_MULTI(1, 4); break;
+      case 2: MQ_MULTI(2, 4); break;
+      case 3: MQ_MULTI(3, 4); break;
+      case 4: MQ_MULTI(4, 4); break;
+      default: return MQ_ERR_UNSUPPORTED;
+    }
+  }
+#undef MQ_MULTI
+  return MQ_OK;
+}
+int MQ_CAT(mq_launch_multi, MQ_PART)(int bf16, int nv, int wpr, dim3 grid, hipStream_t st, const QuantBatch& b) {
+  if (bf16) return launch_multi<MQ_PART - 1, true>(nv, wpr, grid, st, b);
+  return launch_multi<MQ_PART - 1, false>(nv, wpr, grid, st, b);
+}
+#endif
+
 // One format's kernels per translation unit.
-#if MQ_PART >= 1 && !defined(MQ_NP_UNIT)
+#if MQ_PART >= 1 && !defined(MQ_NP_UNIT) && !defined(MQ_MULTI_UNIT)
 #define MQ_PART_FMT (MQ_PART - 1)  // MQ_INT_SYM, MQ_INT_ASYM, MQ_LUT_FP, MQ_LUT_FP_SUB
 #define MQ_CAT2(a, b) a##b
 #define MQ_CAT(a, b) MQ_CAT2(a, b)
@@ -2603,6 +2640,10 @@ int mq_launch_np1(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatc
 int mq_launch_np2(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 int mq_launch_np3(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
 int mq_launch_np4(int, int, int, int, dim3, size_t, hipStream_t, const QuantBatch&);
+int mq_launch_multi1(int, int, int, dim3, hipStream_t, const QuantBatch&);
+int mq_launch_multi2(int, int, int, dim3, hipStream_t, const QuantBatch&);
+int mq_launch_multi3(int, int, int, dim3, hipStream_t, const QuantBatch&);
+int mq_launch_multi4(int, int, int, dim3, hipStream_t, const QuantBatch&);
 
 // ---- optional timing of the full quantize launches (HIP events on the launch stream) ----------------------
 // State of the calling thread: a pool of events that is created outside the timed region (mq_profile_reserve, or
@@ -3219,6 +3260,7 @@ extern "C" int mq_sweep_run(const void* table_dev, int32_t count, int64_t seg_le
 
 #include "mq_feed_host.h"
 #include "mq_np_host.h"
+#include "mq_multi_host.h"
 
 extern "C" size_t mq_tensor_mse_numpy_workspace_bytes(int64_t rows, int64_t cols) {
   const int64_t n = rows * cols;

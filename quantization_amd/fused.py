@@ -207,6 +207,10 @@ class _QuantItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("out", _lib.QuantOut)]
 
 
+class _MultiItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("list", ctypes.c_void_p * 4), ("totals", ctypes.c_void_p * 4)]
+
+
 def bind_batch():
     """libmq.so with the batch entry points' ctypes signatures set."""
     L_ = _lib.lib()
@@ -229,6 +233,15 @@ def bind_batch():
         L_.mq_quantize_p99_passes_workspace_bytes.argtypes = [i32, i32, i64, i64]
         L_.mq_quantize_p99_passes.restype = ctypes.c_int
         L_.mq_quantize_p99_passes.argtypes = [vp, i32, i32, i32, i64, i64, ctypes.c_double, ctypes.c_double, vp, sz, vp]
+        L_.mq_sweep_multi_table_bytes.restype = sz
+        L_.mq_sweep_multi_table_bytes.argtypes = [i32]
+        L_.mq_sweep_multi_workspace_bytes.restype = sz
+        L_.mq_sweep_multi_workspace_bytes.argtypes = [i64]
+        L_.mq_sweep_multi_prepare.restype = ctypes.c_int
+        L_.mq_sweep_multi_prepare.argtypes = [ctypes.POINTER(_MultiItem), ctypes.POINTER(i64), i64, i32, i32,
+                                              ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, ctypes.POINTER(i64)]
+        L_.mq_sweep_multi_run.restype = ctypes.c_int
+        L_.mq_sweep_multi_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, vp]
         L_.mq_sweep_table_bytes.restype = sz
         L_.mq_sweep_table_bytes.argtypes = [i32]
         L_.mq_sweep_workspace_bytes.restype = sz

@@ -280,10 +280,10 @@ class SweepPlan:
     in `mse_tensor` [len(passes), len(weights)] then have the reference's bits."""
 
     def __init__(self, weights, passes, pct: float = 99.0, numpy_order: bool = False, single_launch: bool = True,
-                 feed_lists: bool = False):
+                 feed_lists: bool = False, fuse_groupings: bool = True):
         import ctypes
         import os
-        from .fused import _DTYPES, _QuantItem, bind_batch, make_cfg
+        from .fused import _DTYPES, _MultiItem, _QuantItem, bind_batch, make_cfg
         self.weights = list(weights)
         self.passes = list(passes)
         self.pct = float(pct)
@@ -314,7 +314,34 @@ class SweepPlan:
             single_launch = False
         if os.environ.get("MQ_SWEEP_FEED") in ("0", "1"):   # (measurements either way)
             feed_lists = os.environ["MQ_SWEEP_FEED"] == "1"
-        for datatype, bits, group_size in self.passes:
+        if os.environ.get("MQ_SWEEP_FUSE") in ("0", "1"):   # (measurements either way)
+            fuse_groupings = os.environ["MQ_SWEEP_FUSE"] == "1"
+        # Passes that differ only in the grouping -- per row, groups of 32 / 64 / 128 -- form a family: the layers the
+        # several-groupings launch takes (float16 / bfloat16, a multiple of 128 columns up to 32768) are read ONCE for
+        # all of the family's passes (mq_sweep_multi_run, enqueued with the family's first pass); the passes keep their
+        # own lists, totals, selections and record rows.
+        SLOT = {0: 0, 32: 1, 64: 2, 128: 3}
+        self.families = []
+        fam_of: Dict[int, dict] = {}
+        if fuse_groupings and single_launch and not numpy_order and not feed_lists:
+            by_fmt: Dict[Tuple, Dict[int, int]] = {}
+            for k, (datatype, bits, group_size) in enumerate(self.passes):
+                gs0 = 0 if group_size is None or (group_size <= 0 and group_size != -1) else group_size
+                if gs0 in SLOT and format_code(datatype)[1] not in TABLE_LISTS:
+                    by_fmt.setdefault((datatype, bits), {}).setdefault(SLOT[gs0], k)
+            for slots in by_fmt.values():
+                if len(slots) >= 2:
+                    fam = dict(slots=slots, first=min(slots.values()), pos={})
+                    self.families.append(fam)
+                    for k in slots.values():
+                        fam_of[k] = fam
+
+        def fusable(pos):
+            w = self.weights[self.order[pos]]
+            C = w.shape[1]
+            return (w.dtype in (torch.float16, torch.bfloat16) and C % 128 == 0 and 128 <= C <= 32768
+                    and w.data_ptr() % 16 == 0 and w.numel() * 2 <= 0xF0000000)
+        for k_pass, (datatype, bits, group_size) in enumerate(self.passes):
             fmt, table = format_code(datatype)
             if table in TABLE_LISTS:
                 raise ValueError("SweepPlan: the explicit-list tables go layer by layer (model_records)")
@@ -364,8 +391,12 @@ class SweepPlan:
             # goes in batches of up to 32 same-shaped layers.
             launches = []
             keys: Dict[Tuple, List[int]] = {}
+            fam = fam_of.get(k_pass)
             for pos, i in enumerate(self.order):
                 w = self.weights[i]
+                if fam is not None and fusable(pos):     # (read by the family's launch)
+                    fam["pos"].setdefault((w.dtype, w.shape[1]), set()).add(pos)
+                    continue
                 keys.setdefault((w.dtype, w.shape[1] if gs <= 0 else None), []).append(pos)
             slow_pos = []     # numpy_order: layers whose means come from the per-layer kernels
             for (dtype, _), poss in keys.items():
@@ -458,7 +489,9 @@ class SweepPlan:
             for la in launches:
                 if la[0] == "feedsweep":
                     fed[la[11].cpu()] = True
-            written = [pos for pos in range(nl) if not bool(fed[pos])]
+            # (the lists a family's launch writes are selected from right behind that launch, chunk by chunk)
+            in_family = set().union(*fam["pos"].values()) if fam is not None and fam["pos"] else set()
+            written = [pos for pos in range(nl) if not bool(fed[pos]) and pos not in in_family]
             sel = dict(ptrs=(ctypes.c_void_p * nl)(*ptrs), ns=(ctypes.c_int64 * nl)(*ns), n=nl, idx=None, tmp=None)
             if len(written) < nl:
                 sel = dict(ptrs=(ctypes.c_void_p * len(written))(*[ptrs[pos] for pos in written]),
@@ -466,7 +499,52 @@ class SweepPlan:
                            idx=torch.tensor(written, dtype=torch.int64, device=dev),
                            tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
             self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
-                                  sel=sel, slow_pos=slow_pos, fed=fed))
+                                  sel=sel, slow_pos=slow_pos, fed=fed, ptrs=ptrs, ns=ns))
+        # The families' launches, attached to the family's first pass: per (dtype, column count), in chunks of layers --
+        # the selections over a chunk's lists (every pass of the family) are enqueued right behind its launch and run
+        # on the second stream beside the next chunk's, so only the last chunk's selections follow the last launch.
+        for fam in self.families:
+            mask = sum(1 << c for c in fam["slots"])
+            first = self.plan[fam["first"]]
+            nbytes = lambda pos: self.weights[self.order[pos]].numel() * 2
+            fam_bytes = sum(nbytes(pos) for poss in fam["pos"].values() for pos in poss)
+            chunk_bytes = max(1 << 28, fam_bytes // int(os.environ.get("MQ_SWEEP_CHUNKS", "8")))
+            keys = sorted(fam["pos"].items(), key=lambda kv: -sum(nbytes(pos) for pos in kv[1]))
+            for ki, ((dtype, C), poss) in enumerate(keys):
+                poss = sorted(poss, key=lambda pos: -nbytes(pos))
+                chunks, cur, acc = [], [], 0
+                for pos in poss:
+                    cur.append(pos)
+                    acc += nbytes(pos)
+                    if acc >= chunk_bytes:
+                        chunks.append(cur)
+                        cur, acc = [], 0
+                if cur:
+                    chunks.append(cur)
+                if ki == len(keys) - 1 and len(chunks[-1]) > 1 and sum(nbytes(pos) for pos in chunks[-1]) > chunk_bytes // 3:
+                    # the family's last chunk is a small one: its selections are what follows the last launch
+                    cut = max(1, len(chunks[-1]) // 3)
+                    chunks[-1], tail = chunks[-1][:-cut], chunks[-1][-cut:]
+                    chunks.append(tail)
+                for chunk in chunks:
+                    n = len(chunk)
+                    items = (_MultiItem * n)()
+                    for j, pos in enumerate(chunk):
+                        items[j].w = self.weights[self.order[pos]].data_ptr()
+                        for c, k in fam["slots"].items():
+                            items[j].list[c] = self.plan[k]["ptrs"][pos]
+                            items[j].totals[c] = self.plan[k]["totals"].data_ptr() + pos * 16
+                    rows = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[0] for pos in chunk])
+                    host = torch.empty(L.mq_sweep_multi_table_bytes(n), dtype=torch.uint8)
+                    blocks = ctypes.c_int64(0)
+                    _lib.check(L.mq_sweep_multi_prepare(items, rows, C, n, _DTYPES[dtype], ctypes.byref(first["cfg"]), mask,
+                                                        host.data_ptr(), host.numel(), ctypes.byref(blocks)))
+                    idx = torch.tensor(chunk, dtype=torch.int64, device=dev)
+                    jobs = [dict(k=k, ptrs=(ctypes.c_void_p * n)(*[self.plan[k]["ptrs"][pos] for pos in chunk]),
+                                 ns=(ctypes.c_int64 * n)(*[self.plan[k]["ns"][pos] for pos in chunk]), n=n, idx=idx,
+                                 tmp=torch.zeros(n, dtype=torch.float64, device=dev)) for k in sorted(fam["slots"].values())]
+                    first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, jobs))
+                    self.ws_bytes = max(self.ws_bytes, L.mq_sweep_multi_workspace_bytes(blocks.value))
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
 
     def lists(self, k: int):
@@ -534,8 +612,17 @@ class SweepPlan:
                 cfg = ps["cfg"]
                 if sampled is not None and pre is not main:
                     main.wait_event(sampled)
+                chunk_done = []
                 for la in ps["launches"]:
-                    if la[0] == "npsweep":
+                    if la[0] == "multisweep":
+                        # (each chunk needs the whole workspace: the partial sums of chunk i are added up before chunk
+                        #  i + 1 starts, on this stream)
+                        _lib.check(L.mq_sweep_multi_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
+                                                        la[6], ws.data_ptr(), ws.numel(), main.cuda_stream))
+                        done = torch.cuda.Event()
+                        done.record(main)
+                        chunk_done.append((la, done))
+                    elif la[0] == "npsweep":
                         _lib.check(L.mq_sweep_numpy_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
                                                         ws.data_ptr(), ws.numel(), main.cuda_stream))
                     elif la[0] == "feedsweep":
@@ -553,8 +640,18 @@ class SweepPlan:
                 ready.record(main)
                 sampled = sample(k + 1) if k + 1 < len(self.plan) else None
                 with torch.cuda.stream(side):
-                    side.wait_event(ready)
                     sws, _ = workspace(dev, self.side_ws_bytes)
+                    # the lists of a family's chunks, every pass of the family: chunk i's beside the launch of chunk
+                    # i + 1 (enqueued after ALL of the launches above: the host's calls for them would otherwise hold
+                    # up the next launch)
+                    for la, done in chunk_done:
+                        side.wait_event(done)
+                        for job in la[7]:
+                            _lib.check(L.mq_percentile_multi(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
+                                                             job["tmp"].data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                             side.cuda_stream))
+                            self.plan[job["k"]]["p99"].index_copy_(0, job["idx"], job["tmp"])
+                    side.wait_event(ready)
                     sel = ps["sel"]
                     if sel["n"]:
                         out = ps["p99"] if sel["idx"] is None else sel["tmp"]
@@ -642,7 +739,7 @@ def numpy_order_available(weights, passes) -> bool:
 
 @torch.no_grad()
 def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = None, numpy_order: Optional[bool] = None,
-                return_mse_tensor: bool = False):
+                return_mse_tensor: bool = False, fuse_groupings: bool = True):
     """model_records(weights, datatype, bits, group_size, abs_p99=False) for every (datatype, bits, group_size) of
     `passes`, one shot: float64 [len(passes), len(weights), len(RECORD_FIELDS)] (and, with vecs_of = k, the
     per-vector MSE lists of pass k; with return_mse_tensor the tensor means [len(passes), len(weights)]).  Builds a
@@ -655,7 +752,7 @@ def model_sweep(weights, passes, pct: float = 99.0, vecs_of: Optional[int] = Non
     weights, passes = list(weights), list(passes)
     if numpy_order is None:
         numpy_order = numpy_order_available(weights, passes)
-    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order)
+    plan = SweepPlan(weights, passes, pct, numpy_order=numpy_order, fuse_groupings=fuse_groupings)
     out = plan.run()
     res = [out]
     if vecs_of is not None:

@@ -1,6 +1,8 @@
 """Randomised differential run of the model-sweep entry points: report.SweepPlan (prepared launches, two streams)
 against report.model_records (pass by pass) against report.layer_record (layer by layer), on random sets of
-layer shapes, dtypes and passes: sums and percentiles bit for bit, the list mean to 1e-12.
+layer shapes, dtypes and passes: sums and percentiles bit for bit, the list mean to 1e-12 -- with one launch per
+pass; and the plan that reads a layer once for the passes that differ only in the grouping (the default) against
+that one: to the 1e-6 bar (its sums are taken in another order), the group lists of the integer formats bit for bit.
 run(seconds, seed); as a script: argv = seconds, seed."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +28,7 @@ def run(budget, seed):
         passes = [(FORMATS[rng.integers(len(FORMATS))], 0, [None, 32, 64, 128][rng.integers(4)]) for _ in range(int(rng.integers(1, 5)))]
         passes = [(f, 4 if f in ("int4", "fp4") else 8, gs) for f, _, gs in passes]
         what = f"[{n}] {len(ws)} layers of {shapes} {dt} scale={scale} passes={passes}"
-        plan = report.SweepPlan(ws, passes)
+        plan = report.SweepPlan(ws, passes, fuse_groupings=False)
         for overlap in (True, False):
             got = plan.run(overlap=overlap).clone()
             for k, (f, b, gs) in enumerate(passes):
@@ -36,6 +38,23 @@ def run(budget, seed):
                 assert torch.allclose(got[k][:, 3], want[:, 3], rtol=1e-12, atol=0, equal_nan=True), what + " mse_rep"
                 for a, b_ in zip(plan.lists(k), vecs):
                     assert torch.equal(a.view(torch.int32), b_.view(torch.int32)), what + f" pass {k}: lists differ"
+        # the same passes with the groupings of a format computed from one read
+        fused = report.SweepPlan(ws, passes)
+        for overlap in (True, False):
+            fg = fused.run(overlap=overlap)
+            for k, (f, b, gs) in enumerate(passes):
+                for a, b_ in zip(fused.lists(k), plan.lists(k)):
+                    if gs is not None and f.startswith("int"):   # (a NaN's sign and payload are whatever the last operation left)
+                        ok = (a.view(torch.int32) == b_.view(torch.int32)) | (a.isnan() & b_.isnan())
+                        assert bool(ok.all()), what + f" pass {k}: fused group lists differ"
+                    x, y = a.double(), b_.double()
+                    assert torch.equal(x.isnan(), y.isnan()) and torch.equal(x.isinf(), y.isinf()), what + f" pass {k}: fused list NaN / inf"
+                    fin = y.isfinite()
+                    assert bool(((x[fin] - y[fin]).abs() <= 1e-6 * y[fin].abs()).all()), what + f" pass {k}: fused lists"
+                x, y = fg[k][:, :5], got[k][:, :5]
+                assert torch.equal(x.isnan(), y.isnan()) and torch.equal(x.isinf(), y.isinf()), what + f" pass {k}: fused records NaN / inf"
+                fin = y.isfinite()
+                assert bool(((x[fin] - y[fin]).abs() <= 3e-6 * y[fin].abs()).all()), what + f" pass {k}: fused records"
         # one layer, one pass against the per-layer flow
         k = int(rng.integers(len(passes))); i = int(rng.integers(len(ws)))
         f, b, gs = passes[k]

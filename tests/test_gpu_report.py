@@ -343,12 +343,17 @@ def test_model_sweep_equals_model_records():
     ws = [(torch.randn(*s, generator=g, device="cuda") * 0.02).bfloat16() for s in shapes]
     passes = [("int8", 8, None), ("int8", 8, 32), ("int8_asym", 8, 128), ("fp8_e4m3", 8, 64), ("int8", 8, 128)]
     for _ in range(3):
-        got, vecs = report.model_sweep(ws, passes, vecs_of=1, numpy_order=False)
+        got, vecs = report.model_sweep(ws, passes, vecs_of=1, numpy_order=False, fuse_groupings=False)
         for k, (dt, bits, gs) in enumerate(passes):
             want, wv = report.model_records(ws, dt, bits, gs, abs_p99=False, return_vecs=True)
             assert torch.equal(got[k].view(torch.int64), want.view(torch.int64)), (dt, gs)
             if k == 1:
                 assert all(torch.equal(a, b) for a, b in zip(vecs, wv))
+        # the default reads a layer once for the three int8 passes: the same numbers to the 1e-6 bar, the group lists
+        # of the integer formats bit for bit
+        fg, fvecs = report.model_sweep(ws, passes, vecs_of=1, numpy_order=False)
+        assert all(torch.equal(a, b) for a, b in zip(fvecs, vecs))
+        assert torch.allclose(fg, got, rtol=3e-6, atol=0.0)
     # the default is numpy's summation order wherever the kernels offer it: the numbers of the reference's CSV rows
     assert report.numpy_order_available(ws, passes)
     got, mt = report.model_sweep(ws, passes, return_mse_tensor=True)
@@ -379,7 +384,7 @@ def test_single_launch_sweep_equals_per_shape_batches():
     for weights in (mixed, [w.bfloat16() for w in ws], mixed[:3] + [ws[3].float()] + mixed[4:]):
         passes = [("int8", 8, None), ("int8", 8, 32), ("int8_asym", 8, 64), ("fp8_e4m3", 8, 128), ("fp4", 4, 256),
                   ("int8_asym", 8, None), ("fp8_e3m4", 8, None), ("int4", 4, 512), ("int8", 8, -1), ("int8", 8, 16)]
-        one = report.SweepPlan(weights, passes)
+        one = report.SweepPlan(weights, passes, fuse_groupings=False)
         per = report.SweepPlan(weights, passes, single_launch=False)
         kinds = [{la[0] for la in ps["launches"]} for ps in one.plan]
         assert all(k == {"batch"} for k in ([{la[0] for la in ps["launches"]} for ps in per.plan]))
@@ -489,7 +494,7 @@ def test_list_percentile_selected_inside_the_pass(dist):
     ws[1][7, :64] = float("nan")                       # a tensor whose list holds a NaN: mse_p99 is NaN either way
     passes = [("int8", 8, 32), ("int8_asym", 8, 64), ("fp8_e4m3", 8, 32), ("int8", 8, 128), ("int8", 8, None), ("fp4", 4, 64)]
     fed = report.SweepPlan(ws, passes, feed_lists=True)
-    ref = report.SweepPlan(ws, passes)
+    ref = report.SweepPlan(ws, passes, fuse_groupings=False)
     assert bool(fed.fed(0)[:2].all()) and bool(fed.fed(0)[3]) and not bool(fed.fed(0)[2]) and not bool(fed.fed(0)[4])
     assert not bool(fed.fed(4).any()) and not bool(ref.fed(0).any())       # rows are never fed
     assert bool(fed.fed(1)[3])                                            # g = 64: the large tensors
@@ -516,7 +521,7 @@ def test_list_percentile_survives_a_misleading_sample():
     w.view(-1, 2048)[torch.from_numpy(step.astype(np.int64)).cuda()] = 0
     other = (torch.randn(2048, 4096, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
     fed = report.SweepPlan([w, other], [("int8", 8, gs)], feed_lists=True)
-    ref = report.SweepPlan([w, other], [("int8", 8, gs)])
+    ref = report.SweepPlan([w, other], [("int8", 8, gs)], fuse_groupings=False)
     assert bool(fed.fed(0).all())
     a, b = fed.run().clone(), ref.run().clone()
     torch.cuda.synchronize()
@@ -524,3 +529,50 @@ def test_list_percentile_survives_a_misleading_sample():
     assert float(a[0, 0, 4]) > 0
     # the repaired tensor's list was written after all
     assert torch.equal(fed.lists(0)[0].view(torch.int32), ref.lists(0)[0].view(torch.int32))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_fused_groupings_equal_separate_passes(dt):
+    """SweepPlan reads a layer ONCE for the passes of a format that differ only in the grouping (per row, groups of
+    32 / 64 / 128: mq_sweep_multi_run) -- against the same plan with one launch per pass: every list entry, every
+    record field to the 1e-6 bar of the float64-sum mode (the sums are taken in another order; NaN / inf patterns
+    equal), on whole and ragged rows, short rows, rows a workgroup shares, and rows with inf / NaN / one-sided /
+    clamped-scale segments that leave the fast path."""
+    import numpy as np
+    from quantization_amd import report
+    from test_gpu_stats_kernels import _inputs
+    shapes = [(64, 1024), (16, 4096), (8, 14336), (16, 5632), (32, 11008), (4, 28672), (64, 256), (8, 8192), (32, 1536),
+              (40, 128), (12, 2048), (6, 16384)]
+    ws = []
+    g = torch.Generator().manual_seed(5)
+    for k, (r, c) in enumerate(shapes):
+        w = torch.randn(r, c, generator=g) * 0.02 if k % 2 else _inputs(r, c, 900 + k)
+        ws.append((w.half() if dt == "f16" else w.bfloat16()).cuda())
+    ws.append((torch.randn(8, 1024, generator=g) * 0.02).cuda())      # float32: not fused (the batched launches take it)
+    fams = [("int8", 8), ("int8_asym", 8), ("int4_asym", 4), ("fp8_e4m3", 8), ("fp8_e3m4", 8), ("fp4", 4), ("int2", 2)]
+    passes = [(n, b, gs) for n, b in fams for gs in (None, 32, 64, 128)]
+    passes += [("int6", 6, 32), ("int6", 6, 128), ("int3", 3, None), ("int3", 3, 64), ("int5", 5, 32)]   # partial families, a single pass
+    fused = report.SweepPlan(ws, passes, fuse_groupings=True)
+    plain = report.SweepPlan(ws, passes, fuse_groupings=False)
+    kinds = [la[0] for ps in fused.plan for la in ps["launches"]]
+    assert kinds.count("multisweep") >= 9 * 7, kinds.count("multisweep")
+    assert "multisweep" not in [la[0] for ps in plain.plan for la in ps["launches"]]
+    a, b = fused.run().cpu().numpy(), plain.run().cpu().numpy()
+
+    def close(x, y, what, tol=1e-6):
+        x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        assert np.array_equal(np.isnan(x), np.isnan(y)), what + ": NaN pattern"
+        assert np.array_equal(np.isinf(x), np.isinf(y)), what + ": inf pattern"
+        fin = np.isfinite(y)
+        err = np.abs(x[fin] - y[fin])
+        bad = err > tol * np.abs(y[fin])
+        assert not bad.any(), (what, int(bad.sum()), float(np.max(err / np.maximum(np.abs(y[fin]), 1e-300))))
+
+    for k, ps in enumerate(passes):
+        for i in range(len(ws)):
+            close(fused.lists(k)[i].cpu().numpy(), plain.lists(k)[i].cpu().numpy(), f"{ps} {tuple(ws[i].shape)} list")
+        close(a[k, :, :4], b[k, :, :4], f"{ps} records")
+        close(a[k, :, 4], b[k, :, 4], f"{ps} P99", tol=3e-6)
+    # twice: the plan's buffers are reused
+    a2 = fused.run().cpu().numpy()
+    assert np.array_equal(a, a2, equal_nan=True)

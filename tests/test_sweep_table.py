@@ -16,8 +16,11 @@ class _Item(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("out", _lib.QuantOut)]
 
 
+# (after the block range: the fields of the numpy-order and list-feeding launches, empty in a table of mq_sweep_prepare)
 ENTRY = np.dtype([("w", "<u8"), ("scale", "<u8"), ("zp", "<u8"), ("seg_sse", "<u8"), ("totals", "<u8"),
-                  ("nseg", "<i8"), ("blk0", "<u4"), ("nblk", "<u4"), ("pad", "<i8")])
+                  ("nseg", "<i8"), ("blk0", "<u4"), ("nblk", "<u4"), ("leaf", "<u8"), ("lchunk0", "<u4"), ("pad", "<u4"),
+                  ("feed", "<u8"), ("blo", "<u4"), ("bhi", "<u4"), ("wg_cnt", "<u8"), ("slots", "<u8"), ("sample", "<u8"),
+                  ("sunit", "<u4"), ("scount", "<u4")])
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +53,7 @@ def _prepare(L, shapes, group_size, dtype=_lib.BF16, fmt=_lib.INT_SYM, bits=8, w
     cfg = _lib.QuantCfg(format=fmt, bits=bits, group_size=0 if group_size is None else group_size,
                         exp_bits=4, man_bits=3, exp_bias=7)
     tab = np.zeros(n, dtype=ENTRY)
-    assert L.mq_sweep_table_bytes(n) == tab.nbytes == 64 * n
+    assert L.mq_sweep_table_bytes(n) == tab.nbytes == 120 * n
     seg_len, blocks = ctypes.c_int64(-1), ctypes.c_int64(-1)
     rc = L.mq_sweep_prepare(items, rows, cols, n, dtype, ctypes.byref(cfg), tab.ctypes.data,
                             tab.nbytes if table_bytes is None else table_bytes, ctypes.byref(seg_len), ctypes.byref(blocks))
