@@ -124,7 +124,7 @@ def algorithmic_bytes_per_elem(in_bytes, lut, asym, gs, outputs):
 class ModelSweep:
     """The sharded model sweep (configs [0], [3], [4]): this rank's layers of the model, every pass of the sweep."""
 
-    def __init__(self, name, device, rank, world, dist_name, numpy_order=False):
+    def __init__(self, name, device, rank, world, dist_name, numpy_order=False, fuse=True):
         import torch
         from quantization_amd import shapes
         from quantization_amd.distributed import lpt_partition
@@ -148,15 +148,14 @@ class ModelSweep:
         self.local_weight_bytes = self.local_elems * esz * len(self.passes)
         # every pass of the sweep over this rank's resident layers: launch descriptors and buffers are prepared once
         from quantization_amd.report import SweepPlan
-        self.plan = SweepPlan(self.weights, self.passes, numpy_order=bool(numpy_order)) if self.weights else None
+        self.plan = (SweepPlan(self.weights, self.passes, numpy_order=bool(numpy_order), fuse_groupings=fuse)
+                     if self.weights else None)
         # algorithmic bytes: every weight once per pass, plus the float32 per-vector list where the pass writes it (the
         # list of a large tensor in a per-group pass is not written: its percentile is selected inside the pass)
-        self.local_algo_bytes = 0
-        for k, (f, _, gs) in enumerate(self.passes):
-            fed = self.plan.fed(k) if self.plan is not None else []
-            for j, i in enumerate(self.mine):
-                r, c = self.layers[i][1]
-                self.local_algo_bytes += sizes[i] * esz + (0 if bool(fed[j]) else 4 * (r if gs is None else sizes[i] // gs))
+        # (the passes of a format that differ only in the grouping read a layer ONCE: report.SweepPlan, mq_sweep_multi_run)
+        self.local_algo_bytes = (self.plan.read_bytes + self.plan.list_bytes) if self.plan is not None else 0
+        self.fused = self.plan is not None and bool(self.plan.families)
+        self.local_read_bytes = self.plan.read_bytes if self.plan is not None else 0
         self.launches_hint = sum(-(-sum(1 for i in self.mine if self.layers[i][1] == sh) // 32)
                                  for sh in {self.layers[i][1] for i in self.mine}) * len(self.passes)
         self.n_layers = len(self.layers)
@@ -179,6 +178,13 @@ class ModelSweep:
         self.kernel_desc = ("statistics-only fused quantize pass (k_stats_row / k_stats_group: ONE launch per pass over all of the "
                             "rank's layers whose segments have one length -- per-group passes the whole shard, per-channel passes "
                             "the layers of one column count)")
+        if self.fused:
+            npf = max(len(f["slots"]) for f in self.plan.families)
+            self.kernel_desc = (f"statistics-only fused quantize pass over {npf} groupings per read (k_stats_multi: the passes of a "
+                                "format that differ only in the grouping -- per row, g = 32 / 64 / 128 -- share ONE read of a "
+                                "layer; launches per format and column count, in chunks of layers). achieved counts the bytes the "
+                                "launch moves (each weight once, every list), not once per grouping: the launch is bound by "
+                                "instruction issue, not by HBM")
 
     def step(self):
         import torch
@@ -294,10 +300,11 @@ class Workload:
             # the model-sweep entry point over this GPU's resident tensors; its fed lists are not written (see ModelSweep)
             from quantization_amd.report import SweepPlan
             self.plan = SweepPlan(*self.sweep)
-            ws, ps = self.sweep
-            self.algo_bytes = sum(w.numel() * 2 + (0 if bool(self.plan.fed(k)[j]) else
-                                                   4 * (w.shape[0] if gs is None else w.numel() // gs))
-                                  for k, (_, _, gs) in enumerate(ps) for j, w in enumerate(ws))
+            self.algo_bytes = self.plan.read_bytes + self.plan.list_bytes
+            if self.plan.families:
+                self.kernel_desc = ("statistics-only fused quantize pass over 4 groupings per read (k_stats_multi: per row, "
+                                    "g = 32 / 64 / 128 of one format from ONE read of a layer); achieved counts the bytes the "
+                                    "launch moves, not once per grouping: the launch is bound by instruction issue, not by HBM")
         self.launches = len(self.batches)
         self.device = device
         self.record = torch.zeros(self.tensors, 5, dtype=torch.float64, device=device)
@@ -571,6 +578,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl.desc}",
                        "passes_per_step": len(wl.passes) if sharded else wl.launches,
+                       **({"weight_bytes_read_per_step_rank0": int(wl.local_read_bytes)} if sharded else {}),
                        "weight_bytes_per_step_whole_job": int(total_weight_bytes),
                        "gpu_ms_per_step_events_rank0": round(gpu_ms / args.steps, 4),
                        **({"numpy_order": True} if args.numpy_order else {})},
@@ -580,6 +588,21 @@ def main():
         }
         if isolated:
             out["roofline"]["launch_alone"] = isolated
+        if sharded and world == 1 and getattr(wl, "fused", False) and args.workload == "llama8b" and not args.no_extra:
+            # the same sweep with ONE launch per pass (every pass reads the weights itself): the HBM-bound form, for
+            # comparison -- its own weights and lists, 3 steps outside the headline's timed region
+            w1 = ModelSweep(args.workload, device, rank, world, args.dist, fuse=False)
+            wall1, _, k1, n1 = timed_run(w1.step, 3, 1, device, None, 1, w1.launches_hint)
+            r1 = roofline(w1.local_algo_bytes, 3, k1, n1, "", None)
+            a1 = launch_alone(w1, device, None, 1, w1.launches_hint, w1.local_algo_bytes)
+            out["roofline"]["one_launch_per_pass"] = {
+                "ms_per_step": round(wall1 / 3 * 1e3, 4), "value": round(w1.total_weight_bytes * 3 / wall1 / 1e9, 2),
+                "avg_launch_us": r1["avg_launch_us"], "achieved": r1["achieved"], "frac": r1["frac"],
+                "launch_alone_frac": a1["frac"] if a1 else None,
+                "note": "k_stats_row / k_stats_group, one launch per (format, grouping) pass: each pass streams the weights "
+                        "from HBM again"}
+            del w1
+            torch.cuda.empty_cache()
         if sharded:
             out["config"].update({
                 "backend": backend if world > 1 else "none (one rank)",

@@ -321,6 +321,8 @@ class SweepPlan:
         # all of the family's passes (mq_sweep_multi_run, enqueued with the family's first pass); the passes keep their
         # own lists, totals, selections and record rows.
         SLOT = {0: 0, 32: 1, 64: 2, 128: 3}
+        self.read_bytes = 0    # weight bytes the quantize launches of one run() read (a family's launch reads a layer once)
+        self.list_bytes = 0    # list bytes they write
         self.families = []
         fam_of: Dict[int, dict] = {}
         if fuse_groupings and single_launch and not numpy_order and not feed_lists:
@@ -480,6 +482,8 @@ class SweepPlan:
                         self.ws_bytes = max(self.ws_bytes,
                                             L.mq_quantize_batch_workspace_bytes(len(sel), K, C, ctypes.byref(cfg)))
                         launches.append(("batch", make_items(sel), len(sel), _DTYPES[dtype], K, C))
+            self.read_bytes += sum(self.weights[self.order[pos]].numel() * self.weights[self.order[pos]].element_size()
+                                   for poss in keys.values() for pos in poss)
             params = None
             if numpy_order:
                 params = [(scl[offs[pos]:offs[pos] + ns[pos]],
@@ -498,6 +502,7 @@ class SweepPlan:
                            ns=(ctypes.c_int64 * len(written))(*[ns[pos] for pos in written]), n=len(written),
                            idx=torch.tensor(written, dtype=torch.int64, device=dev),
                            tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
+            self.list_bytes += sum(4 * ns[pos] for pos in range(nl) if not bool(fed[pos]))
             self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
                                   sel=sel, slow_pos=slow_pos, fed=fed, ptrs=ptrs, ns=ns))
         # The families' launches, attached to the family's first pass: per (dtype, column count), in chunks of layers --
@@ -528,6 +533,7 @@ class SweepPlan:
                     chunks.append(tail)
                 for chunk in chunks:
                     n = len(chunk)
+                    self.read_bytes += sum(nbytes(pos) for pos in chunk)
                     items = (_MultiItem * n)()
                     for j, pos in enumerate(chunk):
                         items[j].w = self.weights[self.order[pos]].data_ptr()
