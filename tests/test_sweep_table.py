@@ -152,3 +152,71 @@ def test_numpy_order_entry_points_refuse_bad_arguments_before_any_launch(L):
     assert call(w=w + 2) == U                                                              # weights off the 16-byte grid
     assert call(nb=nb - 1) == _lib.ERR_WORKSPACE and call(ws=None) == _lib.ERR_WORKSPACE
     assert call(cfg=_lib.QuantCfg(format=_lib.INT_SYM, bits=9, group_size=128)) == U
+
+
+# ---- the several-groupings launch (mq_sweep_multi_prepare): host rules, no device ---------------------------------
+class _MultiItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("list", ctypes.c_void_p * 4), ("totals", ctypes.c_void_p * 4)]
+
+
+MULTI_ENTRY = np.dtype([("w", "<u8"), ("list", "<u8", (4,)), ("totals", "<u8", (4,)), ("nrow", "<i8"), ("blk0", "<u4"),
+                        ("nblk", "<u4")])
+
+
+def _multi_prepare(L, rows, cols, mask, dtype=_lib.BF16, fmt=_lib.INT_SYM, bits=8, w_base=0x10000000, table_bytes=None,
+                   list_base=0x7000000000):
+    i32, i64, vp, sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t
+    L.mq_sweep_multi_table_bytes.restype = sz
+    L.mq_sweep_multi_table_bytes.argtypes = [i32]
+    L.mq_sweep_multi_workspace_bytes.restype = sz
+    L.mq_sweep_multi_workspace_bytes.argtypes = [i64]
+    L.mq_sweep_multi_prepare.restype = ctypes.c_int
+    L.mq_sweep_multi_prepare.argtypes = [ctypes.POINTER(_MultiItem), ctypes.POINTER(i64), i64, i32, i32,
+                                         ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, ctypes.POINTER(i64)]
+    n = len(rows)
+    items = (_MultiItem * n)()
+    for j in range(n):
+        items[j].w = w_base + j * 0x8000000
+        for c in range(4):
+            items[j].list[c] = list_base + (4 * j + c) * 0x1000000
+            items[j].totals[c] = 0x7800000000 + (4 * j + c) * 16
+    cfg = _lib.QuantCfg(format=fmt, bits=bits, group_size=0, exp_bits=4, man_bits=3, exp_bias=7)
+    tab = np.zeros(n, dtype=MULTI_ENTRY)
+    assert L.mq_sweep_multi_table_bytes(n) == tab.nbytes == 88 * n
+    blocks = ctypes.c_int64(-1)
+    rc = L.mq_sweep_multi_prepare(items, (ctypes.c_int64 * n)(*rows), cols, n, dtype, ctypes.byref(cfg), mask,
+                                  tab.ctypes.data, tab.nbytes if table_bytes is None else table_bytes, ctypes.byref(blocks))
+    return rc, tab, blocks.value, items
+
+
+def test_multi_table_block_ranges_and_slots(L):
+    rows = [4096, 1, 300, 60000]
+    for cols in (128, 2048, 4096, 5632, 8192, 14336, 28672, 32768):
+        for mask in (15, 3, 12, 9):
+            rc, tab, blocks, items = _multi_prepare(L, rows, cols, mask)
+            assert rc == _lib.OK, (cols, mask)
+            assert tab["blk0"][0] == 0 and blocks == int(tab["nblk"].sum())
+            assert np.array_equal(tab["blk0"][1:], np.cumsum(tab["nblk"])[:-1])
+            assert np.array_equal(tab["nrow"], rows) and (tab["nblk"] >= 1).all()
+            # a workgroup takes about 128 KiB of weights, in whole rows (four at a time where a wave holds a row)
+            per = max(1, (128 * 1024) // (cols * 2) // (1 if cols > 8192 else 4)) * (1 if cols > 8192 else 4)
+            assert np.array_equal(tab["nblk"], [(r + per - 1) // per for r in rows]), cols
+            for c in range(4):   # only the slots of the mask carry pointers
+                want = [(items[j].list[c] or 0) if (mask >> c) & 1 else 0 for j in range(len(rows))]
+                assert np.array_equal(tab["list"][:, c], want) and ((tab["totals"][:, c] != 0) == bool((mask >> c) & 1)).all()
+            assert L.mq_sweep_multi_workspace_bytes(blocks) == blocks * 64
+
+
+def test_multi_table_refusals(L):
+    ok = dict(rows=[64, 64], cols=4096, mask=15)
+    assert _multi_prepare(L, **ok)[0] == _lib.OK
+    assert _multi_prepare(L, [64], 4000, 15)[0] == _lib.ERR_UNSUPPORTED            # not a multiple of 128 columns
+    assert _multi_prepare(L, [64], 64, 15)[0] == _lib.ERR_UNSUPPORTED              # shorter than a group of 128
+    assert _multi_prepare(L, [64], 32768 + 128, 15)[0] == _lib.ERR_UNSUPPORTED     # longer than a workgroup holds
+    assert _multi_prepare(L, [64], 4096, 0)[0] == _lib.ERR_ARG and _multi_prepare(L, [64], 4096, 16)[0] == _lib.ERR_ARG
+    assert _multi_prepare(L, [0], 4096, 15)[0] == _lib.ERR_ARG
+    assert _multi_prepare(L, [64], 4096, 15, dtype=_lib.F32)[0] == _lib.ERR_UNSUPPORTED
+    assert _multi_prepare(L, [64], 4096, 15, w_base=0x10000008)[0] == _lib.ERR_UNSUPPORTED   # weights off the 16-byte grid
+    assert _multi_prepare(L, [64], 4096, 15, list_base=0x7000000002)[0] == _lib.ERR_ALIGN
+    assert _multi_prepare(L, [64, 64], 4096, 15, table_bytes=88)[0] == _lib.ERR_WORKSPACE
+    assert _multi_prepare(L, [300000], 8192, 15)[0] == _lib.ERR_UNSUPPORTED         # past the 32-bit offsets of the loads
