@@ -306,6 +306,7 @@ class SweepPlan:
         self.records = torch.zeros(len(self.passes), nl, len(RECORD_FIELDS), dtype=torch.float64, device=dev)
         # numpy_order: float64 [len(passes), len(weights)], the scripts' mse_tensor bit for bit (filled by run())
         self.mse_tensor = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev) if numpy_order else None
+        self.p99_all = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev)   # row k: pass k's percentiles
         self.ws_bytes = 0
         self.side_ws_bytes = 0
         self.fin_ws_bytes = 1 << 16
@@ -350,7 +351,7 @@ class SweepPlan:
             cfg = make_cfg(fmt, bits, group_size, table)
             gs = cfg.group_size
             totals = torch.zeros(nl, 2, dtype=torch.float64, device=dev)
-            p99 = torch.zeros(nl, dtype=torch.float64, device=dev)
+            p99 = self.p99_all[k_pass]
             # the per-vector MSE lists of the pass: one float32 buffer, every list 32-byte aligned
             ns, offs, total = [], [], 0
             for i in self.order:
@@ -513,7 +514,9 @@ class SweepPlan:
             first = self.plan[fam["first"]]
             nbytes = lambda pos: self.weights[self.order[pos]].numel() * 2
             fam_bytes = sum(nbytes(pos) for poss in fam["pos"].values() for pos in poss)
-            chunk_bytes = max(1 << 28, fam_bytes // int(os.environ.get("MQ_SWEEP_CHUNKS", "8")))
+            # (every chunk costs the host a launch and a selection call: a rank's small share goes in few chunks)
+            chunk_bytes = max(int(os.environ.get("MQ_SWEEP_CHUNK_MB", "768")) << 20,
+                              fam_bytes // int(os.environ.get("MQ_SWEEP_CHUNKS", "8")))
             keys = sorted(fam["pos"].items(), key=lambda kv: -sum(nbytes(pos) for pos in kv[1]))
             for ki, ((dtype, C), poss) in enumerate(keys):
                 poss = sorted(poss, key=lambda pos: -nbytes(pos))
@@ -545,11 +548,16 @@ class SweepPlan:
                     blocks = ctypes.c_int64(0)
                     _lib.check(L.mq_sweep_multi_prepare(items, rows, C, n, _DTYPES[dtype], ctypes.byref(first["cfg"]), mask,
                                                         host.data_ptr(), host.numel(), ctypes.byref(blocks)))
-                    idx = torch.tensor(chunk, dtype=torch.int64, device=dev)
-                    jobs = [dict(k=k, ptrs=(ctypes.c_void_p * n)(*[self.plan[k]["ptrs"][pos] for pos in chunk]),
-                                 ns=(ctypes.c_int64 * n)(*[self.plan[k]["ns"][pos] for pos in chunk]), n=n, idx=idx,
-                                 tmp=torch.zeros(n, dtype=torch.float64, device=dev)) for k in sorted(fam["slots"].values())]
-                    first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, jobs))
+                    # ONE selection call for the chunk's lists of every pass of the family (group lists first: the
+                    # short per-row lists take another route and form their own run), one scatter of the results
+                    members = sorted(fam["slots"].values(), key=lambda k: -self.plan[k]["ns"][chunk[0]])
+                    m = n * len(members)
+                    job = dict(ptrs=(ctypes.c_void_p * m)(*[self.plan[k]["ptrs"][pos] for k in members for pos in chunk]),
+                               ns=(ctypes.c_int64 * m)(*[self.plan[k]["ns"][pos] for k in members for pos in chunk]), n=m,
+                               idx=torch.tensor([k * nl + pos for k in members for pos in chunk], dtype=torch.int64, device=dev),
+                               tmp=torch.zeros(m, dtype=torch.float64, device=dev))
+                    first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, job))
+                    self.side_ws_bytes = max(self.side_ws_bytes, L.mq_percentile_batch_workspace_bytes(min(m, 64)))
                     self.ws_bytes = max(self.ws_bytes, L.mq_sweep_multi_workspace_bytes(blocks.value))
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
 
@@ -650,13 +658,14 @@ class SweepPlan:
                     # the lists of a family's chunks, every pass of the family: chunk i's beside the launch of chunk
                     # i + 1 (enqueued after ALL of the launches above: the host's calls for them would otherwise hold
                     # up the next launch)
+                    flat = self.p99_all.view(-1)
                     for la, done in chunk_done:
                         side.wait_event(done)
-                        for job in la[7]:
-                            _lib.check(L.mq_percentile_multi(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
-                                                             job["tmp"].data_ptr(), None, sws.data_ptr(), sws.numel(),
-                                                             side.cuda_stream))
-                            self.plan[job["k"]]["p99"].index_copy_(0, job["idx"], job["tmp"])
+                        job = la[7]
+                        _lib.check(L.mq_percentile_multi(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
+                                                         job["tmp"].data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                         side.cuda_stream))
+                        flat.index_copy_(0, job["idx"], job["tmp"])
                     side.wait_event(ready)
                     sel = ps["sel"]
                     if sel["n"]:
