@@ -150,6 +150,11 @@ class ModelSweep:
         from quantization_amd.report import SweepPlan
         self.plan = (SweepPlan(self.weights, self.passes, numpy_order=bool(numpy_order), fuse_groupings=fuse)
                      if self.weights else None)
+        # this rank's rows go straight into the whole model's table (every other row zero): the all-reduce needs no
+        # fill and scatter in front of it
+        self.table_mode = self.plan is not None and not numpy_order
+        if self.table_mode:
+            self.plan.set_table(len(self.layers), self.mine)
         # algorithmic bytes: every weight once per pass, plus the float32 per-vector list where the pass writes it (the
         # list of a large tensor in a per-group pass is not written: its percentile is selected inside the pass)
         # (the passes of a format that differ only in the grouping read a layer ONCE: report.SweepPlan, mq_sweep_multi_run)
@@ -188,7 +193,7 @@ class ModelSweep:
 
     def step(self):
         import torch
-        from quantization_amd.distributed import gather_records, joint_percentile
+        from quantization_amd.distributed import gather_records, joint_percentile, reduce_table
         from quantization_amd.report import RECORD_FIELDS, SweepPlan
         local, vecs = None, []
         if self.weights:
@@ -201,7 +206,10 @@ class ModelSweep:
         if self.weights:
             local = self.plan.finish().reshape(-1, len(RECORD_FIELDS))
         # ... and one all-reduce of the zero-filled record table of the whole sweep
-        table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
+        if self.table_mode:
+            table = reduce_table(local)
+        else:
+            table = gather_records(self.index, local, self.n_layers * len(self.passes), len(RECORD_FIELDS), self.device)
         # the statistics leave the device inside the step: the record table (tens of KiB) and the model-wide P99 go
         # to pinned host memory on the step's stream; the timed region ends with a synchronize, so they have arrived
         if self.host_table is None:

@@ -316,6 +316,15 @@ int mq_slice_sum_numpy_f32(const void* const* firsts, int32_t count, int64_t n, 
  */
 int mq_sweep_records(const double* totals, const double* p99, const double* numel, const int64_t* perm, int32_t count,
                      double* records, void* hip_stream);
+/*
+ * The same rows for a whole report table in one launch, gathered instead of scattered: row i of `table` (rows x 6
+ * doubles, EVERY row is written) is the record of source s = src[i] -- numel[s], totals[s][0], totals[s][1],
+ * totals[s][0] / numel[s], p99[p99_index[s]] (NaN when the mean is NaN), 0 -- or six zeros where src[i] < 0: the rows
+ * of layers another GPU holds, which the all-reduce over the ranks' tables fills in (quant_error_multi_weight.py:142-151
+ * run over a model whose layers are sharded).  src NULL: s = i; p99_index NULL: p99[s].  All arrays are device arrays.
+ */
+int mq_sweep_table(const double* totals, const double* p99, const int64_t* p99_index, const double* numel,
+                   const int64_t* src, int32_t rows, double* table, void* hip_stream);
 
 /*
  * Several groupings of ONE format from one read of the weights: the reference's sweeps quantize the same tensor once
@@ -468,6 +477,14 @@ size_t mq_percentile_batch_workspace_bytes(int32_t count);
  * workspace needs mq_percentile_batch_workspace_bytes(min(count, 64)). */
 int mq_percentile_multi(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype, double pct, void* out,
                         void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
+/* mq_percentile_multi for a call enqueued on a stream of its own BESIDE a kernel that fills the chip (the
+ * selections of one chunk of a model sweep beside the statistics launch of the next): identical results, from
+ * 256-thread workgroups where mq_percentile_multi launches 1024-thread ones.  A 1024-thread workgroup needs four
+ * free wave slots on every SIMD of a compute unit at once and waits until the neighbour drains a whole unit; single
+ * waves find room as the neighbour's waves retire.  Alone on the chip mq_percentile_multi is the faster one.  No
+ * counterpart in the reference (its np.percentile calls run one after the other on the host). */
+int mq_percentile_multi_beside(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype, double pct,
+                               void* out, void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct, void* out,
                         void* out_pair, void* workspace, size_t workspace_bytes, void* hip_stream);
 

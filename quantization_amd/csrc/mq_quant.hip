@@ -2377,6 +2377,28 @@ __global__ __launch_bounds__(256) void k_sweep_records(const double* totals, con
   r[5] = 0.0;
 }
 
+// The same rows gathered: row i of the table comes from source src[i] (none: zeros), whose percentile lies at
+// p99[p99_index[source]].  Every row of the table is written.
+__global__ __launch_bounds__(256) void k_sweep_table(const double* totals, const double* p99, const int64_t* p99_index,
+                                                     const double* numel, const int64_t* src, int n, double* table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = src ? src[i] : i;
+  double* r = table + 6 * (int64_t)i;
+  if (s < 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = 0.0;
+    return;
+  }
+  const double sse = totals[2 * s], mse = sse / numel[s];
+  r[0] = numel[s];
+  r[1] = sse;
+  r[2] = totals[2 * s + 1];
+  r[3] = mse;
+  r[4] = mse != mse ? mse : p99[p99_index ? p99_index[s] : s];
+  r[5] = 0.0;
+}
+
 #endif  // MQ_PART == 0
 
 // ================================================================================================
@@ -3367,6 +3389,19 @@ extern "C" int mq_sweep_records(const double* totals, const double* p99, const d
     return MQ_ERR_ALIGN;
   hipLaunchKernelGGL(k_sweep_records, dim3((unsigned)((count + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(hip_stream), totals, p99, numel, perm, (int)count, records);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+
+extern "C" int mq_sweep_table(const double* totals, const double* p99, const int64_t* p99_index, const double* numel,
+                              const int64_t* src, int32_t rows, double* table, void* hip_stream) {
+  if (rows < 0 || (rows > 0 && (!totals || !p99 || !numel || !table))) return MQ_ERR_ARG;
+  if (rows == 0) return MQ_OK;
+  if (!aligned(totals, 8) || !aligned(p99, 8) || !aligned(p99_index, 8) || !aligned(numel, 8) || !aligned(src, 8) ||
+      !aligned(table, 8))
+    return MQ_ERR_ALIGN;
+  hipLaunchKernelGGL(k_sweep_table, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), totals, p99, p99_index, numel, src, (int)rows, table);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }

@@ -271,12 +271,40 @@ __device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r
     const bool same = p0 == p1;
     const uint64_t himask = remaining == (sizeof(T) == 4 ? 31 : 63) ? 0ull : ~((1ull << (shift + width)) - 1ull);
     const uint32_t dmask = (1u << width) - 1u;
-    for (int64_t i = threadIdx.x; i < n; i += THREADS) {
-      const uint64_t key = key_of(x[i]);
+    auto tally = [&](uint64_t key) __attribute__((always_inline)) {
       const uint32_t d = (uint32_t)(key >> shift) & dmask;
       if ((key & himask) == p0) atomicAdd(&hist[0][d], 1u);
       if (!same && (key & himask) == p1) atomicAdd(&hist[1][d], 1u);
+    };
+    // 16-byte loads, four in flight per thread (a 256-thread workgroup walks 32768 values in 32 rounds of single
+    // loads otherwise, each a trip to L2): elements before the first 16-byte boundary and after the last whole
+    // vector one by one
+    constexpr int V = 16 / sizeof(T), U = 4;
+    int64_t head = (int64_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(x) & 15u)) & 15u) / sizeof(T));
+    head = head < n ? head : n;
+    for (int64_t i = threadIdx.x; i < head; i += THREADS) tally(key_of(x[i]));
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x + head);
+    const int64_t nvec = (n - head) / V;
+    for (int64_t v0 = threadIdx.x; v0 < nvec; v0 += U * THREADS) {
+      u32x4 raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        raw[u] = u32x4{0, 0, 0, 0};
+        if (v0 + u * THREADS < nvec) raw[u] = xv[v0 + u * THREADS];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (v0 + u * THREADS >= nvec) break;
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) tally((uint64_t)(raw[u][k] & 0x7fffffffu) << 32);
+        } else {
+          tally((((uint64_t)raw[u][1] << 32) | raw[u][0]) & 0x7fffffffffffffffull);
+          tally((((uint64_t)raw[u][3] << 32) | raw[u][2]) & 0x7fffffffffffffffull);
+        }
+      }
     }
+    for (int64_t i = head + nvec * V + threadIdx.x; i < n; i += THREADS) tally(key_of(x[i]));
     __syncthreads();
     // locate each rank: every thread owns BPT consecutive bins
     for (int r = 0; r < 2; ++r) {
@@ -314,11 +342,11 @@ __device__ __forceinline__ void sel_small_core(const T* x, int64_t n, uint64_t r
   *key0 = s_prefix[0];
   *key1 = s_prefix[1];
 }
-template <typename T>
-__global__ __launch_bounds__(1024) void k_sel_small(const SelBatch b, const SelRanks rk, FinishArgs fin) {
+template <typename T, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_sel_small(const SelBatch b, const SelRanks rk, FinishArgs fin) {
   uint64_t key0, key1;
-  sel_small_core<T>(static_cast<const T*>(b.x[blockIdx.x]), b.n[blockIdx.x], rk.k0[blockIdx.x], rk.k1[blockIdx.x], &key0,
-                    &key1);
+  sel_small_core<T, THREADS>(static_cast<const T*>(b.x[blockIdx.x]), b.n[blockIdx.x], rk.k0[blockIdx.x], rk.k1[blockIdx.x],
+                             &key0, &key1);
   if (threadIdx.x == 0) finish_store(fin, blockIdx.x, key0, key1, rk.gamma[blockIdx.x]);
 }
 
@@ -989,21 +1017,30 @@ static bool bracket_ranks(int64_t n, int64_t k0, int64_t k1, int64_t* m_out, dou
   return bracket_ranks_m(n, *m_out, k0, k1, r_lo, r_hi);
 }
 
+// Workgroup size of the kernels that would otherwise run 1024 threads (the 128 KiB histograms, the one-launch
+// selection of short arrays).  A 1024-thread workgroup wants four wave slots and their registers on every SIMD of a
+// CU at once; beside a kernel that fills the chip it gets them only when a whole CU has drained, i.e. near that
+// kernel's end (measured: 10 .. 20 times its time alone), while a 256-thread workgroup -- one wave per SIMD -- is
+// placed as single waves retire.  Alone on the chip the large workgroups are faster (more loads in flight per
+// histogram): mq_percentile_multi_beside selects the small ones for its call, everything else keeps the large.
+static thread_local int tl_sel_wg_threads = 1024;
+
 static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t dtype, int level, hipStream_t st,
                              int guard = 0) {
   const int V = f32_keys(dtype) ? 4 : 2;
   if (level == 0) {
-    int64_t nb = (nmax / V + 1024 * 4 - 1) / (1024 * 4);
+    const int threads = tl_sel_wg_threads;
+    int64_t nb = (nmax / V + threads * 4 - 1) / (threads * 4);
     int64_t cap = 256 / count < 4 ? 4 : 256 / count;  // one 128 KiB-LDS workgroup fits per CU
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
     if (f32_keys(dtype)) {
       MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<float>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
-      hipLaunchKernelGGL((k_sel_hist_top<float>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
+      hipLaunchKernelGGL((k_sel_hist_top<float>), grid, dim3(threads), SEL_TOP_BINS * 4, st, b, guard);
     } else {
       MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_hist_top<double>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, SEL_TOP_BINS * 4));
-      hipLaunchKernelGGL((k_sel_hist_top<double>), grid, dim3(1024), SEL_TOP_BINS * 4, st, b, guard);
+      hipLaunchKernelGGL((k_sel_hist_top<double>), grid, dim3(threads), SEL_TOP_BINS * 4, st, b, guard);
     }
   } else {
     int64_t nb = (nmax / V + 256 * 4 - 1) / (256 * 4);
@@ -1129,11 +1166,12 @@ static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t
   MQ_HIP(hipGetLastError());
   FinishArgs fin_last = {dtype, out, out_pair};
   if (bracket) {
-    int64_t nb = (mmax / 4 + 1024 * 8 - 1) / (1024 * 8);
+    const int threads = tl_sel_wg_threads;
+    int64_t nb = (mmax / 4 + threads * 8 - 1) / (threads * 8);
     int64_t cap = 256 / c < 2 ? 2 : 256 / c;
     MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
                                SEL_TOP_BINS * 4));
-    hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(1024),
+    hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(threads),
                        SEL_TOP_BINS * 4, st, b);
     hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)c), dim3(256), 0, st, b, sr);
     hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / c < 8 ? 8 : 512 / c), (unsigned)c), dim3(256), 0, st, b);
@@ -1170,8 +1208,13 @@ static int select_small(const void* const* xs, const int64_t* ns, int c, int32_t
     rk.k1[i] = (uint64_t)k1;
   }
   FinishArgs fin = {dtype, out, out_pair};
-  if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_small<float>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
-  else hipLaunchKernelGGL((k_sel_small<double>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+  if (tl_sel_wg_threads == 256) {
+    if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_small<float, 256>), dim3((unsigned)c), dim3(256), 0, st, b, rk, fin);
+    else hipLaunchKernelGGL((k_sel_small<double, 256>), dim3((unsigned)c), dim3(256), 0, st, b, rk, fin);
+  } else {
+    if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_small<float, 1024>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+    else hipLaunchKernelGGL((k_sel_small<double, 1024>), dim3((unsigned)c), dim3(1024), 0, st, b, rk, fin);
+  }
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }
@@ -1221,6 +1264,17 @@ extern "C" int mq_percentile_multi(const void* const* xs, const int64_t* ns, int
 }
 
 // The same for arrays of one length.
+// mq_percentile_multi for a call that runs BESIDE a kernel that fills the chip (on another stream): the same
+// selections with 256-thread workgroups where that one launches 1024-thread ones (tl_sel_wg_threads).
+extern "C" int mq_percentile_multi_beside(const void* const* xs, const int64_t* ns, int32_t count, int32_t dtype,
+                                          double pct, void* out, void* out_pair, void* workspace, size_t workspace_bytes,
+                                          void* hip_stream) {
+  tl_sel_wg_threads = 256;
+  const int rc = mq_percentile_multi(xs, ns, count, dtype, pct, out, out_pair, workspace, workspace_bytes, hip_stream);
+  tl_sel_wg_threads = 1024;
+  return rc;
+}
+
 extern "C" int mq_percentile_batch(const void* const* xs, int32_t count, int32_t dtype, int64_t n, double pct,
                                    void* out, void* out_pair, void* workspace, size_t workspace_bytes,
                                    void* hip_stream) {

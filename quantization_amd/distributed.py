@@ -48,6 +48,18 @@ def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tenso
     return table
 
 
+def reduce_table(table: torch.Tensor, group=None) -> torch.Tensor:
+    """All-reduce (SUM), in place, of a report table in which every rank has written its own layers' rows and zeros
+    everywhere else (report.SweepPlan.set_table): all ranks get the full table.  gather_records without its fill and
+    scatter launches -- the table is complete, zeros included, when the sweep's last launch has run.  One rank, or no
+    process group: the table as it is."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        _drain_for_host_backend(group)
+        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+    return table
+
+
 def analyze_sharded(layers: Sequence, sizes: Sequence[int], analyze_fn: Callable, width: int, device, group=None):
     """layers[i] is whatever analyze_fn needs to produce layer i's record (a float64[width] tensor on
     `device`).  Returns (full table on every rank, indices this rank processed)."""

@@ -41,6 +41,9 @@ def _bind():
     L.mq_percentile_batch_workspace_bytes.argtypes = [i32]
     L.mq_percentile_batch.restype = ctypes.c_int
     L.mq_percentile_batch.argtypes = [ctypes.POINTER(vp), i32, i32, i64, ctypes.c_double, vp, vp, vp, sz, vp]
+    L.mq_percentile_multi_beside.restype = ctypes.c_int
+    L.mq_percentile_multi_beside.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, ctypes.c_double, vp, vp, vp,
+                                             ctypes.c_size_t, vp]
     L.mq_percentile_multi.restype = ctypes.c_int
     L.mq_percentile_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(i64), i32, i32, ctypes.c_double, vp, vp, vp,
                                       sz, vp]
@@ -131,11 +134,13 @@ def percentile_batch(x: torch.Tensor, pct: float = 99.0, wide: bool = False) -> 
 
 @torch.no_grad()
 def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: bool = True,
-                     wide: bool = False) -> torch.Tensor:
+                     wide: bool = False, beside: bool = False) -> torch.Tensor:
     """np.percentile(x, pct) for each of a list of non-negative float32 / float64 device tensors of one dtype
     (any lengths; each flattened; unaligned views are copied): one set of launches per 64 arrays.  nan_check:
     as for percentile() (one small reduction per array; callers that already know which arrays hold a NaN --
-    e.g. from their means -- pass False and patch the results themselves).  wide: as for percentile()."""
+    e.g. from their means -- pass False and patch the results themselves).  wide: as for percentile().
+    beside: the call runs on a stream of its own next to a kernel that fills the chip -- the same results from
+    256-thread workgroups (mq_percentile_multi_beside)."""
     if not xs:
         raise ValueError("percentile_multi() needs at least one array")
     dtype, dev = xs[0].dtype, xs[0].device
@@ -160,8 +165,8 @@ def percentile_multi(xs: Sequence[torch.Tensor], pct: float = 99.0, nan_check: b
     ns = (ctypes.c_int64 * B)(*[x.numel() for x in flat])
     with torch.cuda.device(dev):
         ws, stream = workspace(dev, L.mq_percentile_batch_workspace_bytes(min(B, 64)))
-        st = L.mq_percentile_multi(ptrs, ns, B, code, float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(),
-                                   stream.cuda_stream)
+        fn = L.mq_percentile_multi_beside if beside else L.mq_percentile_multi
+        st = fn(ptrs, ns, B, code, float(pct), out.data_ptr(), None, ws.data_ptr(), ws.numel(), stream.cuda_stream)
     _lib.check(st)
     if has_nan is not None:
         out = torch.where(has_nan, torch.full_like(out, float("nan")), out)

@@ -306,9 +306,19 @@ class SweepPlan:
         self.records = torch.zeros(len(self.passes), nl, len(RECORD_FIELDS), dtype=torch.float64, device=dev)
         # numpy_order: float64 [len(passes), len(weights)], the scripts' mse_tensor bit for bit (filled by run())
         self.mse_tensor = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev) if numpy_order else None
-        self.p99_all = torch.zeros(len(self.passes), nl, dtype=torch.float64, device=dev)   # row k: pass k's percentiles
+        # percentiles: [passes, layers] (row k: pass k's), followed by the results of the families' selection calls (each
+        # call writes one contiguous run; p99_index says where (pass, layer)'s value lies)
+        npass = len(self.passes)
+        self.p99_store = torch.zeros(2 * npass * nl, dtype=torch.float64, device=dev)
+        self.p99_all = self.p99_store[:npass * nl].view(npass, nl)
+        p99_index = list(range(npass * nl))
+        p99_used = npass * nl
+        self.totals_all = torch.zeros(npass, nl, 2, dtype=torch.float64, device=dev)
+        self.table = None     # set_table(): the records go straight into a table over more layers than this plan holds
         self.ws_bytes = 0
         self.side_ws_bytes = 0
+        self.select_beside = os.environ.get("MQ_SWEEP_SELECT_BESIDE", "1") != "0"   # (measurements either way)
+        self.beside_bytes = int(os.environ.get("MQ_SWEEP_BESIDE_MB", "512")) << 20
         self.fin_ws_bytes = 1 << 16
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
@@ -350,7 +360,7 @@ class SweepPlan:
                 raise ValueError("SweepPlan: the explicit-list tables go layer by layer (model_records)")
             cfg = make_cfg(fmt, bits, group_size, table)
             gs = cfg.group_size
-            totals = torch.zeros(nl, 2, dtype=torch.float64, device=dev)
+            totals = self.totals_all[k_pass]
             p99 = self.p99_all[k_pass]
             # the per-vector MSE lists of the pass: one float32 buffer, every list 32-byte aligned
             ns, offs, total = [], [], 0
@@ -529,9 +539,13 @@ class SweepPlan:
                         cur, acc = [], 0
                 if cur:
                     chunks.append(cur)
-                if ki == len(keys) - 1 and len(chunks[-1]) > 1 and sum(nbytes(pos) for pos in chunks[-1]) > chunk_bytes // 3:
+                tail_bytes = int(os.environ.get("MQ_SWEEP_TAIL_MB", "256")) << 20
+                if ki == len(keys) - 1 and len(chunks[-1]) > 1 and sum(nbytes(pos) for pos in chunks[-1]) > 2 * tail_bytes:
                     # the family's last chunk is a small one: its selections are what follows the last launch
-                    cut = max(1, len(chunks[-1]) // 3)
+                    cut, acc = 0, 0
+                    while cut < len(chunks[-1]) - 1 and (cut == 0 or acc + nbytes(chunks[-1][-cut - 1]) <= tail_bytes):
+                        acc += nbytes(chunks[-1][-cut - 1])
+                        cut += 1
                     chunks[-1], tail = chunks[-1][:-cut], chunks[-1][-cut:]
                     chunks.append(tail)
                 for chunk in chunks:
@@ -554,12 +568,39 @@ class SweepPlan:
                     m = n * len(members)
                     job = dict(ptrs=(ctypes.c_void_p * m)(*[self.plan[k]["ptrs"][pos] for k in members for pos in chunk]),
                                ns=(ctypes.c_int64 * m)(*[self.plan[k]["ns"][pos] for k in members for pos in chunk]), n=m,
-                               idx=torch.tensor([k * nl + pos for k in members for pos in chunk], dtype=torch.int64, device=dev),
-                               tmp=torch.zeros(m, dtype=torch.float64, device=dev))
+                               out=self.p99_store[p99_used:p99_used + m],
+                               bytes=sum(nbytes(pos) for pos in chunk))
+                    for j, (k, pos) in enumerate((k, pos) for k in members for pos in chunk):
+                        p99_index[k * nl + pos] = p99_used + j
+                    p99_used += m
                     first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, job))
                     self.side_ws_bytes = max(self.side_ws_bytes, L.mq_percentile_batch_workspace_bytes(min(m, 64)))
                     self.ws_bytes = max(self.ws_bytes, L.mq_sweep_multi_workspace_bytes(blocks.value))
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
+        self.p99_index = torch.tensor(p99_index, dtype=torch.int64, device=dev)
+        self.numel_all = self.numel.repeat(npass)
+        # row (k, order[pos]) of the records <- source k * nl + pos
+        self.set_table(len(self.weights), list(range(len(self.weights))))
+
+    def set_table(self, n_layers: int, layer_ids) -> None:
+        """The records of run() become a table over n_layers layers, float64 [passes, n_layers, fields]: weight i's
+        rows are the rows layer_ids[i], every other row is written as zeros on each run -- the rank's contribution to
+        the all-reduced report table of a sweep whose layers are sharded over GPUs (the default is the plan's own
+        weights in their order).  Not in numpy_order mode, whose passes fill their rows one by one."""
+        nl, npass = len(self.order), len(self.passes)
+        layer_ids = list(layer_ids)
+        if len(layer_ids) != len(self.weights) or len(set(layer_ids)) != len(layer_ids) or \
+                any(not 0 <= g < n_layers for g in layer_ids):
+            raise ValueError("set_table(): one distinct row in [0, n_layers) per weight")
+        if self.numpy_order and (n_layers != len(self.weights) or layer_ids != list(range(n_layers))):
+            raise ValueError("set_table(): not available in numpy_order mode")
+        src = [-1] * (npass * n_layers)
+        for k in range(npass):
+            for pos, i in enumerate(self.order):
+                src[k * n_layers + layer_ids[i]] = k * nl + pos
+        self.table_src = torch.tensor(src, dtype=torch.int64, device=self.dev)
+        if self.records.shape[1] != n_layers:
+            self.records = torch.zeros(npass, n_layers, len(RECORD_FIELDS), dtype=torch.float64, device=self.dev)
 
     def lists(self, k: int):
         return self.plan[k]["lists"]
@@ -653,26 +694,33 @@ class SweepPlan:
                 ready = torch.cuda.Event()
                 ready.record(main)
                 sampled = sample(k + 1) if k + 1 < len(self.plan) else None
+                # Selections that run beside a later launch take the small-workgroup form, which finds room on a busy
+                # chip; those behind the step's last launch have the chip to themselves and take the plain one.
+                later = any(ps2["launches"] for ps2 in self.plan[k + 1:])
+                small = side is not main and self.select_beside
+
+                def select(beside):
+                    return L.mq_percentile_multi_beside if (small and beside) else L.mq_percentile_multi
                 with torch.cuda.stream(side):
                     sws, _ = workspace(dev, self.side_ws_bytes)
                     # the lists of a family's chunks, every pass of the family: chunk i's beside the launch of chunk
                     # i + 1 (enqueued after ALL of the launches above: the host's calls for them would otherwise hold
                     # up the next launch)
-                    flat = self.p99_all.view(-1)
-                    for la, done in chunk_done:
+                    for j, (la, done) in enumerate(chunk_done):
                         side.wait_event(done)
                         job = la[7]
-                        _lib.check(L.mq_percentile_multi(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
-                                                         job["tmp"].data_ptr(), None, sws.data_ptr(), sws.numel(),
-                                                         side.cuda_stream))
-                        flat.index_copy_(0, job["idx"], job["tmp"])
+                        # (beside the NEXT launch; a short one is over before the slower small workgroups are)
+                        nxt = chunk_done[j + 1][0] if j + 1 < len(chunk_done) else None
+                        beside = nxt is not None and nxt[7]["bytes"] >= self.beside_bytes
+                        _lib.check(select(beside)(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
+                                                  job["out"].data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                  side.cuda_stream))
                     side.wait_event(ready)
                     sel = ps["sel"]
                     if sel["n"]:
                         out = ps["p99"] if sel["idx"] is None else sel["tmp"]
-                        _lib.check(L.mq_percentile_multi(sel["ptrs"], sel["ns"], sel["n"], _lib.F32_AS_F64, self.pct,
-                                                         out.data_ptr(), None, sws.data_ptr(), sws.numel(),
-                                                         side.cuda_stream))
+                        _lib.check(select(later)(sel["ptrs"], sel["ns"], sel["n"], _lib.F32_AS_F64, self.pct,
+                                                 out.data_ptr(), None, sws.data_ptr(), sws.numel(), side.cuda_stream))
                         if sel["idx"] is not None:
                             ps["p99"].index_copy_(0, sel["idx"], out)
                     for la in ps["launches"]:   # the fed lists: the wanted ranks among the kept entries
@@ -680,10 +728,17 @@ class SweepPlan:
                             _lib.check(L.mq_sweep_feed_finish(la[6].data_ptr(), la[7], la[3], la[8], la[5], ctypes.byref(cfg),
                                                               la[9].data_ptr(), la[12].data_ptr(), side.cuda_stream))
                             ps["p99"].index_copy_(0, la[11], la[12][la[10]])
-                    # the pass's rows of the record table (one launch: mean = sse / numel, NaN lists, row order)
-                    _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
-                                                  self.perm.data_ptr(), nl, self.records[k].data_ptr(),
-                                                  side.cuda_stream))
+                    # the rows of the record table (mean = sse / numel, NaN lists, row order): every pass's in ONE launch
+                    # behind the last pass -- or pass by pass in numpy_order mode, whose means follow on a third stream
+                    if self.numpy_order:
+                        _lib.check(L.mq_sweep_records(ps["totals"].data_ptr(), ps["p99"].data_ptr(), self.numel.data_ptr(),
+                                                      self.perm.data_ptr(), nl, self.records[k].data_ptr(),
+                                                      side.cuda_stream))
+                    elif k + 1 == len(self.plan):
+                        _lib.check(L.mq_sweep_table(self.totals_all.data_ptr(), self.p99_store.data_ptr(),
+                                                    self.p99_index.data_ptr(), self.numel_all.data_ptr(),
+                                                    self.table_src.data_ptr(), self.table_src.numel(),
+                                                    self.records.data_ptr(), side.cuda_stream))
                     rec_done = None
                     if self.numpy_order:
                         rec_done = torch.cuda.Event()

@@ -576,3 +576,60 @@ def test_fused_groupings_equal_separate_passes(dt):
     # twice: the plan's buffers are reused
     a2 = fused.run().cpu().numpy()
     assert np.array_equal(a, a2, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_percentiles_beside_a_busy_chip_equal_the_plain_call(dtype):
+    """mq_percentile_multi_beside (256-thread workgroups, for calls that run next to a chip-filling kernel) against
+    mq_percentile_multi and numpy: every route -- one-launch short arrays, two-pass histograms, sample + bracket --
+    bit for bit, also while another stream keeps the chip busy."""
+    from quantization_amd.error_metrics import percentile_multi
+    rng = np.random.default_rng(12)
+    lens = [1, 2, 7, 100, 2048, 4096, 32768, 32769, 100000, 1 << 20]
+    if dtype == torch.float32:
+        lens += [(1 << 21) + 5, 5_000_000]
+    arrs = [(rng.standard_normal(n) ** 2 * 10.0 ** rng.uniform(-8, -3)).astype(np.float32 if dtype == torch.float32 else np.float64)
+            for n in lens]
+    arrs[4][:1000] = 0.0                      # ties
+    dev = [torch.from_numpy(a).cuda() for a in arrs]
+    for pct in (99.0, 50.0, 0.0, 100.0):
+        want = np.array([np.percentile(a, pct) for a in arrs], dtype=arrs[0].dtype)
+        plain = percentile_multi(dev, pct, nan_check=False).cpu().numpy()
+        beside = percentile_multi(dev, pct, nan_check=False, beside=True).cpu().numpy()
+        assert plain.tobytes() == want.tobytes()
+        assert beside.tobytes() == want.tobytes(), (pct, beside, want)
+    # next to a long-running neighbour on another stream
+    big = torch.randn(64, 4096, 4096, device="cuda", dtype=torch.float16)
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        for _ in range(4):
+            big.mul_(1.0001)
+    beside = percentile_multi(dev, 99.0, nan_check=False, beside=True).cpu().numpy()
+    torch.cuda.synchronize()
+    assert beside.tobytes() == np.array([np.percentile(a, 99.0) for a in arrs], dtype=arrs[0].dtype).tobytes()
+
+
+def test_records_written_straight_into_a_larger_table():
+    """SweepPlan.set_table: the plan's rows land in the rows of a table over more layers, every other row is zero on
+    EVERY run (the table is all-reduced in place between runs), and the rows equal the plain plan's."""
+    from quantization_amd import report
+    ws = _feed_weights()
+    passes = [("int8", 8, None), ("int8", 8, 32), ("int8", 8, 128), ("fp8_e4m3", 8, 64)]
+    want = report.SweepPlan(ws, passes).run().cpu().numpy()
+    plan = report.SweepPlan(ws, passes)
+    ids = [7, 0, 3, 11, 4]
+    plan.set_table(12, ids)
+    for rep in range(2):
+        got = plan.run()
+        torch.cuda.synchronize()
+        g = got.cpu().numpy()
+        assert g.shape == (len(passes), 12, len(report.RECORD_FIELDS))
+        for i, row in enumerate(ids):
+            assert g[:, row].tobytes() == want[:, i].tobytes()
+        others = [r for r in range(12) if r not in ids]
+        assert not g[:, others].any()
+        got.add_(1.0)      # what an in-place all-reduce leaves behind must not survive the next run
+    with pytest.raises(ValueError):
+        plan.set_table(4, ids)
+    with pytest.raises(ValueError):
+        plan.set_table(12, [1, 1, 2, 3, 4])
