@@ -261,6 +261,19 @@ int mq_sweep_numpy_prepare(const mq_quant_item* items, const int64_t* rows, cons
                            int64_t* list_chunks);
 int mq_sweep_numpy_run(const void* table_dev, int32_t count, int64_t seg_len, int64_t total_blocks, int32_t w_dtype,
                        const mq_quant_cfg* cfg, void* workspace, size_t workspace_bytes, void* hip_stream);
+/*
+ * The launches of up to three numpy-order passes of ONE format whose group sizes are 32, 64 and 128, from one read of
+ * the weights: table32 / 64 / 128_dev are the device copies of the tables mq_sweep_numpy_prepare wrote for those group
+ * sizes over the SAME tensors in the same order (NULL: size not wanted; at least two), total_blocks what any of those
+ * calls returned (it does not depend on the group size).  Every output -- list entries, leaf sums, scales,
+ * zero-points, totals -- has the bits mq_sweep_numpy_run writes for that table; each pass is finished with its own
+ * mq_sweep_numpy_finish as before.  (sweep_quant_error_to_csv.py's --group-sizes loop, one weight read instead of
+ * one per size.)  Workspace: mq_sweep_numpy_groups_workspace_bytes(total_blocks).
+ */
+size_t mq_sweep_numpy_groups_workspace_bytes(int64_t total_blocks);
+int mq_sweep_numpy_run_groups(const void* table32_dev, const void* table64_dev, const void* table128_dev, int32_t count,
+                              int64_t total_blocks, int32_t w_dtype, const mq_quant_cfg* cfg, void* workspace,
+                              size_t workspace_bytes, void* hip_stream);
 size_t mq_sweep_numpy_finish_workspace_bytes(int64_t total_leaves, int64_t list_chunks);
 int mq_sweep_numpy_finish(const void* table_dev, int32_t count, int64_t seg_len, const float* leaf_sums,
                           int64_t total_leaves, int64_t list_chunks, float* mse_tensor, double* mse_rep,

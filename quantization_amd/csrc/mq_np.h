@@ -390,6 +390,224 @@ __global__ __launch_bounds__(256) void k_np_group(const QuantBatch b) {
   block_partials(p, acc_sse, acc_abs, lds);
 }
 
+// ---- groups of 32, 64 AND 128 elements from one read --------------------------------------------------------------
+// The passes of a sweep that differ only in the group size read the same weights, exchange them through LDS the same
+// way and differ from the words W[] on.  This kernel does the load and the exchange once and then runs k_np_group's
+// step for every group size the launch asks for (b.np_tabs[c]: the pass's own launch table for groups of 32 << c, null
+// when the size is not wanted; the tables list the same tensors with the same workgroup ranges -- a step is 4 KiB
+// whatever the group size).  Every list entry, leaf sum, scale, zero-point and total is what k_np_group<FMT, BF16,
+// 1 << c> writes.  Partial sums of size c: b.sweep_partials + 2 * (c * gridDim.x + blockIdx.x).
+template <int FMT, bool BF16>
+__global__ __launch_bounds__(256) void k_np_group3(const QuantBatch b) {
+  QuantParams p = b.common;
+  __shared__ double lds[32];
+  __shared__ __attribute__((aligned(16))) uint32_t xch[4][16 * MQ_NP_LEAF_WORDS];
+  const int first_c = b.np_tabs[0] ? 0 : b.np_tabs[1] ? 1 : 2;
+  int ti;
+  {
+    const SweepItem* tab = b.np_tabs[first_c];
+    int lo = 0, hi = b.sweep_count - 1;
+    while (lo < hi) {  // the last entry whose first workgroup is not past this one (uniform: scalar loads)
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].blk0 <= blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    ti = lo;
+    const SweepItem& it = tab[lo];
+    p.w = it.w;
+    p.n = it.nseg * (32 << first_c);
+    p.bx = blockIdx.x - it.blk0;
+    p.gx = it.nblk;
+  }
+  const int lane = threadIdx.x & 63, q = lane >> 2, m = lane & 3;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t gw = (int64_t)p.bx * 4 + wv, nwaves = (int64_t)p.gx * 4;
+  const int64_t steps = p.n >> 11;
+  uint32_t* reg = xch[wv];
+  const __amdgpu_buffer_rsrc_t rs = stats_rsrc(p);
+  const uint32_t loff = (uint32_t)lane * 16u;
+  double acc_sse[3] = {0.0, 0.0, 0.0}, acc_abs[3] = {0.0, 0.0, 0.0};
+  uint32_t seen_slow = 0u;  // bit c: some step of this wave holds a group of size c off the fast path
+
+  auto issue = [&](int64_t t, u32x4* dst) __attribute__((always_inline)) {
+    const uint32_t base = (uint32_t)(t * 4096) + loff;  // (past the tensor: zeros, no access -- prefetches only)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j] = stats_bload<true>(rs, base + j * 1024);
+  };
+  auto exchange = [&](const u32x4* buf, uint32_t* W) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<u32x4*>(&reg[(4 * j + (lane >> 4)) * MQ_NP_LEAF_WORDS + (lane & 15) * 4]) = buf[j];
+    np_lds_order();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) W[k] = reg[q * MQ_NP_LEAF_WORDS + 4 * k + m];
+    np_lds_order();
+    if constexpr (BF16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) W[k] = bf16x2_to_f16(W[k]);
+    }
+  };
+  // One group size over the words of a step.  SLOW = false: the fast path, nothing is done (and false returned) when a
+  // group of the wave's step is off it; SLOW = true: only such steps, element by element.
+  auto run = [&](auto tc, auto slowc, int64_t t, const uint32_t* W) __attribute__((always_inline)) -> bool {
+    constexpr int T = decltype(tc)::value, C = T == 1 ? 0 : T == 2 ? 1 : 2;
+    constexpr bool SLOW = decltype(slowc)::value;
+    constexpr int NG = 4 / T, WPG = 4 * T;
+    const SweepItem& it = b.np_tabs[C][ti];
+    float* const ent_out = reinterpret_cast<float*>(it.seg_sse);
+    const float inv_len = 1.0f / (float)(32 * T);
+    // the parameters of the group this lane computes (group m / T of the leaf)
+    uint32_t red[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      uint32_t r = np_words_reduce<FMT, WPG>(W + g * WPG);
+      r = stats_op<FMT>(r, dpp<DPP_XOR1>(r));
+      red[g] = stats_op<FMT>(r, dpp<DPP_XOR2>(r));
+    }
+    uint32_t mine = red[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) mine = (m / T) == g ? red[g] : mine;
+    const SegP sp = stats_params<FMT>(mine, p);
+    uint32_t zpb = h_bits(sp.zp);
+    const bool all_fast = __builtin_amdgcn_ballot_w64(sp.slow) == 0ull;
+    if (SLOW == all_fast) return all_fast;
+    if constexpr (FMT == MQ_INT_ASYM && T == 1) {
+      // the sign of a zero zero-point of a 32-element group (see zp_bits_first_zero): lane m holds word m of every
+      // vector, elements 8 (k % 4) + 2 m and + 1 of group k / 4
+      const bool need = zpb == 0u && (mine & 0xffffu) == 0x8000u;
+      if (it.zp && __builtin_amdgcn_ballot_w64(need) != 0ull) {
+        bool plus_first = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          uint32_t fp = 0xffffu, fm = 0xffffu;
+#pragma unroll
+          for (int k = WPG - 1; k >= 0; --k) {
+            const uint32_t w = W[g * WPG + k], e0 = (uint32_t)(8 * k + 2 * m);
+            fp = (w >> 16) == 0u ? e0 + 1u : fp;
+            fm = (w >> 16) == 0x8000u ? e0 + 1u : fm;
+            fp = (w & 0xffffu) == 0u ? e0 : fp;
+            fm = (w & 0xffffu) == 0x8000u ? e0 : fm;
+          }
+          fp = op_min_u32(fp, dpp<DPP_XOR1>(fp)); fp = op_min_u32(fp, dpp<DPP_XOR2>(fp));
+          fm = op_min_u32(fm, dpp<DPP_XOR1>(fm)); fm = op_min_u32(fm, dpp<DPP_XOR2>(fm));
+          plus_first = m == g ? fp < fm : plus_first;
+        }
+        zpb = (need && plus_first) ? 0x8000u : zpb;
+      }
+    }
+    const NpSeg own = np_seg<FMT>(sp);
+    float flo = 0.f, fhi = 0.f, ab = 0.f;
+    float ent[NG];
+    if constexpr (!SLOW) {
+      NpSeg G[NG];
+      if constexpr (NG == 1) { G[0] = own; }
+      else if constexpr (NG == 2) { G[0] = np_seg_from<FMT, 0>(own); G[1] = np_seg_from<FMT, 2>(own); }
+      else { G[0] = np_seg_from<FMT, 0>(own); G[1] = np_seg_from<FMT, 1>(own); G[2] = np_seg_from<FMT, 2>(own);
+             G[3] = np_seg_from<FMT, 3>(own); }
+      float rlo = 0.f, rhi = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int g = k / WPG;
+        uint32_t epk;
+        float e0, e1;
+        np_word_fast<FMT>(p, W[k], G[g], epk, e0, e1);
+        np_chain_fast<FMT>(flo, fhi, epk, e0, e1);
+        if (g > 0) np_chain_fast<FMT>(rlo, rhi, epk, e0, e1);
+        np_abs_fast<FMT>(ab, epk, e0, e1);
+        if ((k + 1) % WPG == 0) {
+          ent[g] = np_quad_tree(g == 0 ? flo + fhi : rlo + rhi);
+          rlo = 0.f;
+          rhi = 0.f;
+        }
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // every word by the per-element routine (equal to the fast path where that applies), squares rounded to float32
+      // as numpy's diff * diff, then added
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        NpSeg sg;  // group g's scale and zero-point, from the lane that computed them
+        sg.szp = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane & ~3) + g * T) * 4, (int)own.szp);
+        float rlo = 0.f, rhi = 0.f;
+#pragma unroll 1
+        for (int k = g * WPG; k < (g + 1) * WPG; ++k) {
+          uint32_t vw = W[0];  // W[k] without indexing the register array by a run-time k
+#pragma unroll
+          for (int kk = 1; kk < 16; ++kk) vw = kk == k ? W[kk] : vw;
+          float e0, e1;
+          np_word_slow<FMT>(p, vw, sg, e0, e1);
+          const float s0 = e0 * e0, s1 = e1 * e1;
+          flo += s0; fhi += s1;
+          rlo += s0; rhi += s1;
+          ab += __builtin_fabsf(e0) + __builtin_fabsf(e1);
+        }
+        ent[g] = np_quad_tree(rlo + rhi);
+      }
+    }
+    const float leaf = NG == 1 ? ent[0] : np_quad_tree(flo + fhi);
+    // entries, leaf sum, parameters -> memory
+    const int64_t lf = t * 16 + q;
+    float mine_ent = ent[0];
+#pragma unroll
+    for (int g = 1; g < NG; ++g) mine_ent = m == g ? ent[g] : mine_ent;
+    if (m < NG) {
+      if (ent_out) ent_out[lf * NG + m] = mine_ent * inv_len;
+    }
+    if ((m % T) == 0) {  // the lane that computed group m / T's parameters
+      if (it.scale) it.scale[lf * NG + m / T] = (uint16_t)h_bits(sp.s);
+      if (FMT == MQ_INT_ASYM && it.zp) it.zp[lf * NG + m / T] = (uint16_t)zpb;
+    }
+    if (m == 0) {
+      if (it.leaf) it.leaf[lf] = leaf;
+      acc_sse[C] += (double)leaf;
+    }
+    acc_abs[C] += (double)ab;
+    return all_fast;
+  };
+  using std::integral_constant;
+  auto step = [&](int64_t t, const u32x4* buf) __attribute__((always_inline)) {
+    uint32_t W[16];
+    exchange(buf, W);
+    if (b.np_tabs[0] && !run(integral_constant<int, 1>{}, integral_constant<bool, false>{}, t, W)) seen_slow |= 1u;
+    if (b.np_tabs[1] && !run(integral_constant<int, 2>{}, integral_constant<bool, false>{}, t, W)) seen_slow |= 2u;
+    if (b.np_tabs[2] && !run(integral_constant<int, 4>{}, integral_constant<bool, false>{}, t, W)) seen_slow |= 4u;
+  };
+  {
+    u32x4 bufa[4], bufb[4];
+    int64_t t = gw;
+    issue(t, bufa);
+    while (t < steps) {
+      const int64_t t1 = t + nwaves, t2 = t1 + nwaves;
+      issue(t1, bufb);
+      step(t, bufa);
+      if (t1 >= steps) break;
+      issue(t2, bufa);
+      step(t1, bufb);
+      t = t2;
+    }
+  }
+  seen_slow = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen_slow);  // (every flag came from a ballot: uniform)
+  if (__builtin_expect(seen_slow != 0u, 0)) {
+#pragma unroll 1
+    for (int64_t t = gw; t < steps; t += nwaves) {
+      u32x4 buf[4];
+      issue(t, buf);
+      uint32_t W[16];
+      exchange(buf, W);
+      if (seen_slow & 1u) run(integral_constant<int, 1>{}, integral_constant<bool, true>{}, t, W);
+      if (seen_slow & 2u) run(integral_constant<int, 2>{}, integral_constant<bool, true>{}, t, W);
+      if (seen_slow & 4u) run(integral_constant<int, 4>{}, integral_constant<bool, true>{}, t, W);
+    }
+  }
+  p.bx = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (!b.np_tabs[c]) continue;
+    p.partials = b.sweep_partials + 2 * ((int64_t)c * gridDim.x + blockIdx.x);
+    block_partials(p, acc_sse[c], acc_abs[c], lds);
+  }
+}
+
 // ---- rows of 2048 * S elements, S = 1, 2, 4 ---------------------------------------------------------------------
 // A wave per row: the row is S wave steps of the group kernel (16 leaves each) and at most one chunk of numpy's
 // summation, a perfect tree -- everything after the one LDS exchange stays in registers: the words of all S steps
@@ -732,6 +950,7 @@ static int launch_np(int scope, int nv, int team_log2, dim3 grid, size_t lds_byt
   } while (0)
   if (scope == SC_STATS_GROUP) {
     switch (team_log2) {
+      case -1: hipLaunchKernelGGL((k_np_group3<FMT, BF16>), grid, dim3(256), 0, st, p); break;  // several sizes per read
       case 0: hipLaunchKernelGGL((k_np_group<FMT, BF16, 1>), grid, dim3(256), 0, st, p); break;
       case 1: hipLaunchKernelGGL((k_np_group<FMT, BF16, 2>), grid, dim3(256), 0, st, p); break;
       default: hipLaunchKernelGGL((k_np_group<FMT, BF16, 4>), grid, dim3(256), 0, st, p); break;

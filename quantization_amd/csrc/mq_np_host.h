@@ -385,6 +385,65 @@ extern "C" int mq_sweep_numpy_run(const void* table_dev, int32_t count, int64_t 
   return MQ_OK;
 }
 
+// The passes of one format with groups of 32, 64 and 128 elements from ONE read of the weights (k_np_group3): tables
+// of mq_sweep_numpy_prepare calls over the same tensors with those group sizes (null: size not wanted; at least two).
+extern "C" size_t mq_sweep_numpy_groups_workspace_bytes(int64_t total_blocks) { return 3 * mq_sweep_workspace_bytes(total_blocks); }
+extern "C" int mq_sweep_numpy_run_groups(const void* table32_dev, const void* table64_dev, const void* table128_dev,
+                                         int32_t count, int64_t total_blocks, int32_t w_dtype, const mq_quant_cfg* cfg,
+                                         void* workspace, size_t workspace_bytes, void* hip_stream) {
+  const void* tabs[3] = {table32_dev, table64_dev, table128_dev};
+  const int wanted = (tabs[0] ? 1 : 0) + (tabs[1] ? 1 : 0) + (tabs[2] ? 1 : 0);
+  if (wanted < 2 || count < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll / 3) return MQ_ERR_ARG;
+  if (int rc = sweep_check_cfg(w_dtype, cfg)) return rc;
+  if (!workspace || workspace_bytes < mq_sweep_numpy_groups_workspace_bytes(total_blocks)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 16) || !aligned(tabs[0], 16) || !aligned(tabs[1], 16) || !aligned(tabs[2], 16)) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  QuantBatch b = {};
+  QuantParams& p = b.common;
+  p.in_dtype = w_dtype;
+  p.L = 32;
+  p.vecs_per_seg = 4;
+  const int fmt = cfg->format;
+  if (fmt == MQ_INT_SYM) p.qmax = (float)((1 << (cfg->bits - 1)) - 1);
+  else if (fmt == MQ_INT_ASYM) p.qmax = (float)((1 << cfg->bits) - 1);
+  else if (!lut_consts(cfg, false, &p.lut, &p.qmax)) return MQ_ERR_UNSUPPORTED;
+  p.rqmax = 1.0f / p.qmax;
+  p.qmax_recip_ok = recip_ok_cached(p.qmax);
+  p.need_err = 1;
+  p.seg_exact = 1;
+  p.sel_mode = SEL_FEED_OFF;
+  for (int c = 0; c < 3; ++c) b.np_tabs[c] = static_cast<const SweepItem*>(tabs[c]);
+  b.sweep_count = count;
+  b.sweep_partials = static_cast<double*>(workspace);
+  hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+  if (prof_on) {
+    if (int rc = prof_next_pair(&prof_e0, &prof_e1)) return rc;
+    MQ_HIP(hipEventRecord(prof_e0, st));
+  }
+  const dim3 grid((unsigned)total_blocks);
+  const int bf16 = w_dtype == MQ_BF16 ? 1 : 0;
+  int rc;
+  switch (fmt) {
+    case MQ_INT_SYM: rc = mq_launch_np1(bf16, SC_STATS_GROUP, -4, -1, grid, 0, st, b); break;
+    case MQ_INT_ASYM: rc = mq_launch_np2(bf16, SC_STATS_GROUP, -4, -1, grid, 0, st, b); break;
+    case MQ_LUT_FP: rc = mq_launch_np3(bf16, SC_STATS_GROUP, -4, -1, grid, 0, st, b); break;
+    default: rc = mq_launch_np4(bf16, SC_STATS_GROUP, -4, -1, grid, 0, st, b); break;
+  }
+  if (rc) return rc;
+  MQ_HIP(hipGetLastError());
+  if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
+  for (int c = 0; c < 3; ++c) {  // each size's totals from its own partial sums
+    if (!tabs[c]) continue;
+    QuantBatch f = {};
+    f.sweep = static_cast<const SweepItem*>(tabs[c]);
+    f.sweep_count = count;
+    f.sweep_partials = static_cast<double*>(workspace) + 2 * (int64_t)c * total_blocks;
+    hipLaunchKernelGGL(k_finalize_sweep, dim3((unsigned)count), dim3(256), 0, st, f);
+    MQ_HIP(hipGetLastError());
+  }
+  return MQ_OK;
+}
+
 static size_t np_finish_lcs_offset(int64_t total_leaves) { return np_align16((size_t)(total_leaves / 64 + 1) * sizeof(float)); }
 extern "C" size_t mq_sweep_numpy_finish_workspace_bytes(int64_t total_leaves, int64_t list_chunks) {
   return np_finish_lcs_offset(total_leaves < 0 ? 0 : total_leaves) + (size_t)((list_chunks < 0 ? 0 : list_chunks) + 1) * sizeof(double);

@@ -26,6 +26,7 @@
 // kernels; MQ_PART 1 / 2 / 3 / 4 hold the kernel instantiations of one format each (symmetric INT, asymmetric INT,
 // value tables without / with subnormals) behind mq_launch_fmt<N>(), so that a clean build runs in parallel.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "mq_common.h"
 #include "mq_sel.h"
@@ -161,6 +162,7 @@ struct QuantBatch {
   NumpyProg np;        // SC_STATS_ROWNP only
   const SweepItem* sweep;  // non-null: a sweep launch (sweep_count entries sorted by blk0); item[] is unused
   const struct NpRowProg* rowprog;  // numpy-order row kernels: the row's summation program (device memory)
+  const SweepItem* np_tabs[3];      // k_np_group3: the launch tables of the passes with groups of 32 / 64 / 128 (or null)
   const struct MultiItem* multi;    // k_stats_multi: the launch's tensors (device memory, sorted by blk0) ...
   int32_t multi_count;              // ... how many, and which groupings are computed (bit 0 rows, 1 .. 3: groups of
   uint32_t multi_mask;              //     32 / 64 / 128); sweep_partials holds 8 doubles per workgroup then

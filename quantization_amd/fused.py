@@ -289,6 +289,10 @@ def bind_batch():
         L_.mq_sweep_feed_finish.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, vp, vp]
         L_.mq_sweep_records.restype = ctypes.c_int
         L_.mq_sweep_records.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+        L_.mq_sweep_numpy_groups_workspace_bytes.restype = ctypes.c_size_t
+        L_.mq_sweep_numpy_groups_workspace_bytes.argtypes = [i64]
+        L_.mq_sweep_numpy_run_groups.restype = ctypes.c_int
+        L_.mq_sweep_numpy_run_groups.argtypes = [vp, vp, vp, i32, i64, i32, ctypes.POINTER(_lib.QuantCfg), vp, sz, vp]
         L_.mq_sweep_table.restype = ctypes.c_int
         L_.mq_sweep_table.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp]
         L_._batch_bound = True

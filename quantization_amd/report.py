@@ -576,6 +576,37 @@ class SweepPlan:
                     first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, job))
                     self.side_ws_bytes = max(self.side_ws_bytes, L.mq_percentile_batch_workspace_bytes(min(m, 64)))
                     self.ws_bytes = max(self.ws_bytes, L.mq_sweep_multi_workspace_bytes(blocks.value))
+        # numpy order: the passes of one format with groups of 32 / 64 / 128 share ONE read too (mq_sweep_numpy_run_groups:
+        # their launch tables list the same tensors in the same order); each pass keeps its own finishing launches
+        self.np_families = 0
+        if numpy_order and fuse_groupings and single_launch:
+            by_fmt: Dict[Tuple, Dict[int, int]] = {}
+            for k, (datatype, bits, group_size) in enumerate(self.passes):
+                if group_size in (32, 64, 128):
+                    by_fmt.setdefault((datatype, bits), {}).setdefault(group_size, k)
+            for sizes in by_fmt.values():
+                if len(sizes) < 2:
+                    continue
+                first = min(sizes.values())
+                per_dt: Dict[int, Dict[int, tuple]] = {}
+                for gsz, k in sizes.items():
+                    for j, la in enumerate(self.plan[k]["launches"]):
+                        if la[0] == "npsweep" and la[3] == gsz:
+                            per_dt.setdefault(la[5], {})[gsz] = (k, j, la)
+                for dt, found in per_dt.items():
+                    las = [v[2] for v in found.values()]
+                    if len(found) < 2 or any(la[2] != las[0][2] or la[4] != las[0][4] or
+                                             not torch.equal(la[9], las[0][9]) for la in las):
+                        continue
+                    tabs = [found[g][2][1] if g in found else None for g in (32, 64, 128)]
+                    n, blocks = las[0][2], las[0][4]
+                    for gsz, (k, j, la) in found.items():
+                        self.plan[k]["launches"][j] = ("npsweep_fused",) + tuple(la[1:])
+                    self.plan[first]["launches"].insert(0, ("npgroups", tabs, n, blocks, dt))
+                    self.ws_bytes = max(self.ws_bytes, L.mq_sweep_numpy_groups_workspace_bytes(blocks))
+                    wbytes = sum(self.weights[int(i)].numel() * 2 for i in las[0][9].cpu().tolist())
+                    self.read_bytes -= (len(found) - 1) * wbytes
+                    self.np_families += 1
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
         self.p99_index = torch.tensor(p99_index, dtype=torch.int64, device=dev)
         self.numel_all = self.numel.repeat(npass)
@@ -680,6 +711,12 @@ class SweepPlan:
                     elif la[0] == "npsweep":
                         _lib.check(L.mq_sweep_numpy_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
                                                         ws.data_ptr(), ws.numel(), main.cuda_stream))
+                    elif la[0] == "npgroups":
+                        t32, t64, t128 = (None if t is None else t.data_ptr() for t in la[1])
+                        _lib.check(L.mq_sweep_numpy_run_groups(t32, t64, t128, la[2], la[3], la[4], ctypes.byref(cfg),
+                                                               ws.data_ptr(), ws.numel(), main.cuda_stream))
+                    elif la[0] == "npsweep_fused":
+                        pass      # (written by the family's npgroups launch)
                     elif la[0] == "feedsweep":
                         _lib.check(L.mq_sweep_feed_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
                                                        ws.data_ptr(), ws.numel(), main.cuda_stream))
@@ -754,7 +791,7 @@ class SweepPlan:
                         done = []
                         # from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
                         for la in ps["launches"]:
-                            if la[0] != "npsweep":
+                            if la[0] not in ("npsweep", "npsweep_fused"):
                                 continue
                             _, tab, n, seg_len, _, _, leaf, tl, lc, widx, rep, mt = la
                             _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,

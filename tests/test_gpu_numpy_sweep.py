@@ -40,7 +40,9 @@ SMALL = [(64, 1024), (16, 4096), (8, 14336), (16, 5632), (32, 11008), (4, 28672)
          (64, 512), (32, 1536)]
 PASSES = [("int8", 8, 32), ("int8", 8, 64), ("int8", 8, 128), ("int8", 8, None), ("int8_asym", 8, 32), ("int8_asym", 8, None),
           ("int4_asym", 4, 128), ("fp8_e4m3", 8, 64), ("fp8_e4m3", 8, None), ("fp8_e3m4", 8, 128), ("fp4", 4, 32),
-          ("fp4", 4, None), ("int2", 2, 64), ("int8", 8, 256), ("fp8_e3m4", 8, 256)]
+          ("fp4", 4, None), ("int2", 2, 64), ("int8", 8, 256), ("fp8_e3m4", 8, 256),
+          # (second and third group sizes of a format: those passes share one read, k_np_group3)
+          ("int8_asym", 8, 128), ("fp8_e4m3", 8, 32), ("fp4", 4, 64)]
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
@@ -62,10 +64,11 @@ def test_numpy_sweep_small_shapes(oracle, dt):
     mt = plan.mse_tensor.cpu().numpy()
     fast = 0
     for k, (name, bits, gs) in enumerate(PASSES):
-        kinds = [la[0] for la in plan.plan[k]["launches"]]
-        fast += kinds.count("npsweep")
+        kinds = [la[0] for la in plan.plan[k]["launches"] if la[0] != "npgroups"]
+        fast += kinds.count("npsweep") + kinds.count("npsweep_fused")
         if gs in (32, 64, 128):   # one numpy-order launch takes every layer of a per-group pass
-            assert kinds == ["npsweep"], (name, gs, kinds)
+            shared = sum(1 for n2, b2, g2 in PASSES if (n2, b2) == (name, bits) and g2 in (32, 64, 128)) > 1
+            assert kinds == ["npsweep_fused" if shared else "npsweep"], (name, gs, kinds)
         (_, _), oargs = _fmt(oracle, _lib, name, bits)
         for i, wt in enumerate(ws16):
             rows, cols = wt.shape
@@ -104,7 +107,8 @@ def _full_size_case(oracle, shape, name, bits, groupings, seed):
     (_, _), oargs = _fmt(oracle, _lib, name, bits)
     out = []
     for k, gs in enumerate(groupings):
-        assert [la[0] for la in plan.plan[k]["launches"]] == ["npsweep"]
+        shared = gs is not None and sum(1 for g2 in groupings if g2 is not None) > 1
+        assert [la[0] for la in plan.plan[k]["launches"] if la[0] != "npgroups"] == ["npsweep_fused" if shared else "npsweep"]
         exp = oracle.quantize(raw, oracle.BF16, group_size=gs, nthreads=16, **oargs)
         b = exp["deq"].view(np.float16).astype(np.float32).reshape(shape)
         d = a - b
@@ -145,3 +149,38 @@ def test_numpy_sweep_lm_head(oracle):
     """The 128256 x 4096 lm_head of Llama-3-8B (525 M elements, 64 128 chunks in numpy's float32 tensor sum)."""
     for gs, (d_mt, d_rep, d_p99) in _full_size_case(oracle, (128256, 4096), "int8", 8, [32, None], 12):
         assert d_mt < 2e-5 and d_rep < 1e-6 and d_p99 < 1e-6, (gs, d_mt, d_rep, d_p99)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_group_sizes_sharing_one_read_equal_separate_launches(dt):
+    """numpy order: the passes of a format with groups of 32 / 64 / 128 from one read (mq_sweep_numpy_run_groups) against
+    one launch per pass: lists, records and tensor means bit for bit -- every format, two and three sizes, weights
+    with segments off the fast path."""
+    from quantization_amd import report
+    g = torch.Generator(device="cuda").manual_seed(77)
+    ws = []
+    for shape in [(1024, 4096), (512, 14336), (256, 2048), (4096, 1024)]:
+        w = torch.randn(*shape, generator=g, device="cuda") * 0.02
+        ws.append(w)
+    ws[0][3, 64:96] = 0.0                # an all-zero group of 32
+    ws[1][7, 128:256] = 1.0              # one-sided groups (asymmetric: off the fast path)
+    ws[2][5, 17] = float("inf")
+    ws[2][9, 300] = float("nan")
+    ws[3][100, :64] = -0.0
+    ws[3][100, 1] = 0.0
+    ws = [w.to(dt) for w in ws]
+    for passes in ([("int8", 8, 32), ("int8", 8, 64), ("int8", 8, 128), ("int8", 8, None)],
+                   [("int8_asym", 8, 128), ("int8_asym", 8, 32), ("fp8_e4m3", 8, 64), ("fp8_e4m3", 8, 128)],
+                   [("fp8_e3m4", 8, 32), ("fp8_e3m4", 8, 64), ("fp4", 4, 32), ("fp4", 4, 128), ("int4_asym", 4, 64),
+                    ("int4_asym", 4, 128)]):
+        a = report.SweepPlan(ws, passes, numpy_order=True, fuse_groupings=False)
+        c = report.SweepPlan(ws, passes, numpy_order=True)
+        assert a.np_families == 0 and c.np_families == len({(n, b) for n, b, gs in passes if gs})
+        ra, rc = a.run().cpu().numpy(), c.run().cpu().numpy()
+        torch.cuda.synchronize()
+        assert ra.tobytes() == rc.tobytes(), passes
+        assert a.mse_tensor.cpu().numpy().tobytes() == c.mse_tensor.cpu().numpy().tobytes(), passes
+        for k in range(len(passes)):
+            for i in range(len(ws)):
+                assert a.lists(k)[i].cpu().numpy().tobytes() == c.lists(k)[i].cpu().numpy().tobytes(), (passes[k], i)
+        assert c.read_bytes < a.read_bytes
