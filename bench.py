@@ -492,6 +492,18 @@ def traffic_for(name):
     return None
 
 
+def issue_for(name):
+    """The vector ALUs' busy fraction under the workload's dominant kernel, from the committed SQ counter pass
+    (scripts/issue_from_pmc.py): what bounds a launch whose HBM fraction is low on purpose."""
+    ipath = os.path.join(ROOT, "profiles", "issue.json")
+    if os.path.exists(ipath):
+        d = json.load(open(ipath)).get(name)
+        if d and d.get("valu_busy") is not None:
+            return {"valu_busy": d["valu_busy"], "source": "rocprofv3 --pmc SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE ... "
+                    "(profiles/issue.json): SIMD cycles with a vector instruction executing / all SIMD cycles of the launch"}
+    return None
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -596,6 +608,8 @@ def main():
         }
         if isolated:
             out["roofline"]["launch_alone"] = isolated
+        if world == 1 and not args.numpy_order and issue_for(args.workload):
+            out["roofline"]["issue"] = issue_for(args.workload)
         if sharded and world == 1 and getattr(wl, "fused", False) and args.workload == "llama8b" and not args.no_extra:
             # the same sweep with ONE launch per pass (every pass reads the weights itself): the HBM-bound form, for
             # comparison -- its own weights and lists, 3 steps outside the headline's timed region
@@ -644,6 +658,8 @@ def main():
                 "roofline": roofline(algo, steps, k2, n2, w2.kernel_desc, traffic_for(name))}
             if name in MODEL_OF or w2.sweep is not None:
                 out["extra"][key]["roofline"]["launch_alone"] = launch_alone(w2, device, None, 1, hint, algo)
+            if issue_for(name):
+                out["extra"][key]["roofline"]["issue"] = issue_for(name)
             del w2
             torch.cuda.empty_cache()
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

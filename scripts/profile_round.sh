@@ -2,7 +2,8 @@
 # Collects the per-workload rocprofv3 evidence the profiles/ directory holds, on a GPU box:
 #   scripts/profile_round.sh <out dir under gpurun_out/> [workload ...]
 # per workload: one --kernel-trace --stats run of bench.py (kernel_stats.csv + bench.py's own line under the
-# trace) and two separate counter runs (FETCH_SIZE, WRITE_SIZE), reduced by scripts/traffic_from_pmc.py.
+# trace), two separate counter runs (FETCH_SIZE, WRITE_SIZE), reduced by scripts/traffic_from_pmc.py, and one run
+# with the SQ issue counters, reduced by scripts/issue_from_pmc.py.
 # Every GPU step runs under its own time limit and the script stops at the first failure.
 set -e -o pipefail
 out=${1:?out dir}; shift
@@ -23,10 +24,17 @@ for w in $wls; do
     timeout -s KILL 280 rocprofv3 --pmc $c -f csv -d "$out/pmc_${c}_$w" -o pmc -- \
         python3 bench.py $flags --steps 1 --warmup 1 > "$out/pmc_${c}_$w.json" 2> "$out/pmc_${c}_$w.log"
   done
+  echo "== $w: SQ counters"
+  timeout -s KILL 280 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
+      -f csv -d "$out/pmc_SQ_$w" -o pmc -- \
+      python3 bench.py $flags --steps 1 --warmup 1 > "$out/pmc_SQ_$w.json" 2> "$out/pmc_SQ_$w.log"
+  python3 scripts/issue_from_pmc.py "$(find "$out/pmc_SQ_$w" -name '*counter_collection.csv' | head -1)" "$w" > "$out/${w}_sq_issue.txt"
+  rm -rf "$out/pmc_SQ_$w"
   python3 scripts/traffic_from_pmc.py "$(find "$out/pmc_FETCH_SIZE_$w" -name '*counter_collection.csv' | head -1)" \
       "$(find "$out/pmc_WRITE_SIZE_$w" -name '*counter_collection.csv' | head -1)" "$w" > "$out/${w}_pmc_traffic.txt"
   # the raw traces are large: only the summaries travel back
   rm -rf "$out/kt_$w" "$out/pmc_FETCH_SIZE_$w" "$out/pmc_WRITE_SIZE_$w"
 done
 cp profiles/traffic.json "$out/traffic.json"
+cp profiles/issue.json "$out/issue.json"
 echo done
