@@ -9,7 +9,10 @@ the chip; GRBM_GUI_ACTIVE counts cycles summed over the 8 XCDs; the chip has 102
     valu_busy = 4 * SQ_ACTIVE_INST_VALU / (1024 * GRBM_GUI_ACTIVE / 8)
 is the fraction of all SIMD cycles of the launch in which a vector instruction was executing, and
 4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU the mean issue cost of one (about 4 cycles for a wave of 64 on 16 lanes).
-A launch near 1.0 is bound by instruction issue whatever its HBM fraction says.  Writes profiles/issue.json."""
+The counter charges every vector instruction one quad-cycle (the quotient comes out at 4.01 .. 4.04 for every kernel
+here), so a stream of instructions that really issue in ~2.4 cycles (v_and_b32, plain float32) reads a little high and
+one with 8-cycle instructions (v_rcp_f32) a little low: valu_busy can pass 1.0 by a few percent.  A launch near 1.0 is
+bound by instruction issue whatever its HBM fraction says.  Writes profiles/issue.json."""
 import csv
 import json
 import os
