@@ -55,6 +55,18 @@ def run(budget, seed):
                 assert torch.equal(x.isnan(), y.isnan()) and torch.equal(x.isinf(), y.isinf()), what + f" pass {k}: fused records NaN / inf"
                 fin = y.isfinite()
                 assert bool(((x[fin] - y[fin]).abs() <= 3e-6 * y[fin].abs()).all()), what + f" pass {k}: fused records"
+        # numpy order (where the kernels offer it for these weights): the group sizes of a format from one read against
+        # one launch per pass, everything bit for bit
+        if report.numpy_order_available(ws, passes) and rng.integers(2) == 0:
+            a = report.SweepPlan(ws, passes, numpy_order=True, fuse_groupings=False)
+            c = report.SweepPlan(ws, passes, numpy_order=True)
+            ra, rc = a.run(), c.run()
+            torch.cuda.synchronize()
+            assert torch.equal(ra.view(torch.int64), rc.view(torch.int64)), what + " numpy order: records differ"
+            assert torch.equal(a.mse_tensor.view(torch.int64), c.mse_tensor.view(torch.int64)), what + " numpy order: mse_tensor"
+            for k in range(len(passes)):
+                for x, y in zip(a.lists(k), c.lists(k)):
+                    assert torch.equal(x.view(torch.int32), y.view(torch.int32)), what + f" numpy order pass {k}: lists differ"
         # one layer, one pass against the per-layer flow
         k = int(rng.integers(len(passes))); i = int(rng.integers(len(ws)))
         f, b, gs = passes[k]
