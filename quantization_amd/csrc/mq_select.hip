@@ -109,6 +109,113 @@ __global__ __launch_bounds__(1024) void k_sel_hist_top(const SelBatch b, int gua
   flush_top(lh, ws->top, ws->top_coarse);
 }
 
+// ---- level 0 in 9 KiB of LDS: for launches that run beside a kernel which leaves no room for 128 KiB --------------------
+// A window of SEL_WINDOW consecutive level-0 counters, placed so that the largest key among the workgroup's first
+// vectors lies at least 256 counters under its top, plus the counters 0 .. 255 (exact zeros are common in error
+// data, and one global counter taking every workgroup's zeros serialises them in one L2 channel).  Keys outside both
+// go to the global counters directly: rare for the data this library selects from (squared-error means and absolute
+// errors of one tensor span a few binades, 128 counters each), slow but exact for anything else.  256 threads.
+#define SEL_WINDOW 2048
+// clears lh[SEL_WINDOW + 256] and returns the window's first counter; mx: this thread's largest level-0 bin so far
+__device__ __forceinline__ uint32_t win_setup(uint32_t* lh, uint32_t* wmax /*[4]*/, uint32_t mx) {
+  for (int i = threadIdx.x; i < SEL_WINDOW + 256; i += blockDim.x) lh[i] = 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o; }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = wmax[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) mx = mx > wmax[w] ? mx : wmax[w];
+  // a multiple of 256 (a wave's 64 consecutive counters then share one coarse counter in the flush)
+  uint32_t top = ((mx + 256u) | 255u) + 1u;
+  top = top > (uint32_t)SEL_TOP_BINS ? (uint32_t)SEL_TOP_BINS : top;
+  return top > (uint32_t)SEL_WINDOW ? top - (uint32_t)SEL_WINDOW : 0u;
+}
+__device__ __forceinline__ void win_put(uint32_t* lh, uint32_t base, uint32_t* fine, uint32_t* coarse, uint32_t bin) {
+  const uint32_t rel = bin - base;
+  if (rel < (uint32_t)SEL_WINDOW) {
+    atomicAdd(&lh[rel], 1u);
+  } else if (bin < 256u) {
+    atomicAdd(&lh[SEL_WINDOW + bin], 1u);
+  } else {
+    atomicAdd(&fine[bin], 1u);
+    atomicAdd(&coarse[bin >> 8], 1u);
+  }
+}
+__device__ __forceinline__ void win_flush(const uint32_t* lh, uint32_t base, uint32_t* fine, uint32_t* coarse) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < SEL_WINDOW; i += blockDim.x) {
+    const uint32_t c = lh[i];
+    if (__builtin_amdgcn_ballot_w64(c != 0u) == 0ull) continue;
+    if (c) atomicAdd(&fine[base + i], c);
+    uint32_t sum = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&coarse[(base + i) >> 8], sum);
+  }
+  if (base >= 256u) {  // (otherwise the window holds those counters itself)
+    const uint32_t c = lh[SEL_WINDOW + threadIdx.x];
+    if (c) atomicAdd(&fine[threadIdx.x], c);
+    uint32_t sum = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&coarse[0], sum);
+  }
+}
+// level-0 bins of the keys in one 16-byte vector
+template <typename T>
+__device__ __forceinline__ void top_bins(const u32x4& raw, uint32_t* bins) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bins[i] = (raw[i] >> 16) & 0x7fffu;
+  } else {
+    bins[0] = (raw[1] >> 16) & 0x7fffu;
+    bins[1] = (raw[3] >> 16) & 0x7fffu;
+  }
+}
+// k_sel_hist_top with the windowed histogram
+template <typename T>
+__global__ __launch_bounds__(256) void k_sel_hist_top_window(const SelBatch b, int guard) {
+  __shared__ uint32_t lh[SEL_WINDOW + 256];
+  __shared__ uint32_t wmax[4];
+  const T* x = static_cast<const T*>(b.x[blockIdx.y]);
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  const int64_t n = b.n[blockIdx.y];
+  if (guard && ws->ok) return;
+  constexpr int V = 16 / sizeof(T);
+  const int64_t nvec = n / V;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  uint32_t mx = 0;
+  if (t0 < nvec) {
+    uint32_t bins[V];
+    top_bins<T>(reinterpret_cast<const u32x4*>(x)[t0], bins);
+#pragma unroll
+    for (int i = 0; i < V; ++i) mx = mx > bins[i] ? mx : bins[i];
+  }
+  const uint32_t base = win_setup(lh, wmax, mx);
+  __syncthreads();
+  constexpr int U = 4;  // loads in flight per lane
+  for (int64_t v0 = t0; v0 < nvec; v0 += U * step) {
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * step;
+      raw[u] = u32x4{0, 0, 0, 0};
+      if (v < nvec) raw[u] = reinterpret_cast<const u32x4*>(x)[v];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (v0 + u * step >= nvec) break;
+      uint32_t bins[V];
+      top_bins<T>(raw[u], bins);
+#pragma unroll
+      for (int i = 0; i < V; ++i) win_put(lh, base, ws->top, ws->top_coarse, bins[i]);
+    }
+  }
+  for (int64_t i = nvec * V + t0; i < n; i += step) win_put(lh, base, ws->top, ws->top_coarse, (uint32_t)(key_of(x[i]) >> 48));
+  win_flush(lh, base, ws->top, ws->top_coarse);
+}
+
 // ---- scan: which bin holds each remaining rank -----------------------------------------------------
 // One 256-thread workgroup per array: locate the rank among the coarse counters, then among the 256
 // fine bins under that counter.  With fin.dtype >= 0 the last level also performs numpy's interpolation
@@ -586,6 +693,50 @@ __global__ __launch_bounds__(1024) void k_sel_sample(const SelBatch b) {
   flush_top(lh, ws->samp, ws->samp_coarse);
 }
 
+// k_sel_sample with the windowed histogram (256 threads)
+__global__ __launch_bounds__(256) void k_sel_sample_window(const SelBatch b) {
+  __shared__ uint32_t lh[SEL_WINDOW + 256];
+  __shared__ uint32_t wmax[4];
+  const u32x4* x = static_cast<const u32x4*>(b.x[blockIdx.y]);
+  SelWs* ws = batch_ws(b, blockIdx.y);
+  const int64_t nchunks = b.n[blockIdx.y] / (SEL_CHUNK_LINES * 64);  // 64 float32 per line
+  const int64_t total = nchunks * 16;                    // 16 lanes x 16 bytes read one line
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  auto load = [&](int64_t i) {
+    const int64_t c = i >> 4;
+    return x[c * (SEL_CHUNK_LINES * 16) + sample_line((uint32_t)c) * 16 + ((uint32_t)i & 15u)];
+  };
+  uint32_t mx = 0;
+  if (t0 < total) {
+    uint32_t bins[4];
+    top_bins<float>(load(t0), bins);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mx = mx > bins[i] ? mx : bins[i];
+  }
+  const uint32_t base = win_setup(lh, wmax, mx);
+  __syncthreads();
+  constexpr int U = 8;  // scattered lines: keep 8 loads in flight per lane
+  for (int64_t i0 = t0; i0 < total; i0 += U * step) {
+    u32x4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * step;
+      raw[u] = u32x4{0, 0, 0, 0};
+      if (i < total) raw[u] = load(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (i0 + u * step < total) {
+        uint32_t bins[4];
+        top_bins<float>(raw[u], bins);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win_put(lh, base, ws->samp, ws->samp_coarse, bins[k]);
+      }
+    }
+  }
+  win_flush(lh, base, ws->samp, ws->samp_coarse);
+}
+
 // Level-0 histogram of the samples a feeding kernel stored (top 16 bits of each value, m per array), 256 threads and
 // 9 KiB of LDS per workgroup: a window of 2048 consecutive counters, placed so that the largest of the workgroup's
 // first samples sits at least 256 counters under its top (the samples of an error array thin out by half per 128
@@ -1030,6 +1181,16 @@ static int launch_accumulate(const SelBatch& b, int count, int64_t nmax, int32_t
   const int V = f32_keys(dtype) ? 4 : 2;
   if (level == 0) {
     const int threads = tl_sel_wg_threads;
+    static const int capk = getenv("MQ_SEL_WINCAP") ? atoi(getenv("MQ_SEL_WINCAP")) : 512;
+    if (threads == 256 && capk > 0) {  // beside a busy chip: the 9 KiB windowed histogram, several workgroups per CU
+      int64_t nb = (nmax / V + 256 * 16 - 1) / (256 * 16);
+      int64_t cap = capk / count < 4 ? 4 : capk / count;
+      dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
+      if (f32_keys(dtype)) hipLaunchKernelGGL((k_sel_hist_top_window<float>), grid, dim3(256), 0, st, b, guard);
+      else hipLaunchKernelGGL((k_sel_hist_top_window<double>), grid, dim3(256), 0, st, b, guard);
+      MQ_HIP(hipGetLastError());
+      return MQ_OK;
+    }
     int64_t nb = (nmax / V + threads * 4 - 1) / (threads * 4);
     int64_t cap = 256 / count < 4 ? 4 : 256 / count;  // one 128 KiB-LDS workgroup fits per CU
     dim3 grid((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)count);
@@ -1166,17 +1327,23 @@ static int select_group(const void* const* xs, const int64_t* ns, int c, int32_t
   MQ_HIP(hipGetLastError());
   FinishArgs fin_last = {dtype, out, out_pair};
   if (bracket) {
-    const int threads = tl_sel_wg_threads;
-    int64_t nb = (mmax / 4 + threads * 8 - 1) / (threads * 8);
-    int64_t cap = 256 / c < 2 ? 2 : 256 / c;
-    MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SEL_TOP_BINS * 4));
-    hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(threads),
-                       SEL_TOP_BINS * 4, st, b);
+    if (tl_sel_wg_threads == 256) {
+      int64_t nb = (mmax / 4 + 256 * 8 - 1) / (256 * 8);
+      int64_t cap = 1024 / c < 8 ? 8 : 1024 / c;
+      hipLaunchKernelGGL(k_sel_sample_window, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(256), 0,
+                         st, b);
+    } else {
+      int64_t nb = (mmax / 4 + 1024 * 8 - 1) / (1024 * 8);
+      int64_t cap = 256 / c < 2 ? 2 : 256 / c;
+      MQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sel_sample), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 SEL_TOP_BINS * 4));
+      hipLaunchKernelGGL(k_sel_sample, dim3((unsigned)(nb < 1 ? 1 : (nb > cap ? cap : nb)), (unsigned)c), dim3(1024),
+                         SEL_TOP_BINS * 4, st, b);
+    }
     hipLaunchKernelGGL(k_sel_scan_sample, dim3((unsigned)c), dim3(256), 0, st, b, sr);
     hipLaunchKernelGGL(k_sel_clear_bracket, dim3((unsigned)(512 / c < 8 ? 8 : 512 / c), (unsigned)c), dim3(256), 0, st, b);
-    nb = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
-    cap = 2048 / c < 16 ? 16 : 2048 / c;
+    int64_t nb = (nmax / 4 + 256 * 8 - 1) / (256 * 8);
+    int64_t cap = 2048 / c < 16 ? 16 : 2048 / c;
     hipLaunchKernelGGL(k_sel_bracket, dim3((unsigned)(nb > cap ? cap : nb), (unsigned)c), dim3(256), 0, st, b);
     hipLaunchKernelGGL(k_sel_scan_bracket, dim3((unsigned)c), dim3(256), 0, st, b, rk, fin_last, 0);
     MQ_HIP(hipGetLastError());

@@ -515,7 +515,7 @@ class SweepPlan:
                            tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
             self.list_bytes += sum(4 * ns[pos] for pos in range(nl) if not bool(fed[pos]))
             self.plan.append(dict(cfg=cfg, totals=totals, p99=p99, launches=launches, lists=lists, mse=mse, params=params,
-                                  sel=sel, slow_pos=slow_pos, fed=fed, ptrs=ptrs, ns=ns))
+                                  sel=sel, slow_pos=slow_pos, fed=fed, ptrs=ptrs, ns=ns, written=written, np_chunks=[]))
         # The families' launches, attached to the family's first pass: per (dtype, column count), in chunks of layers --
         # the selections over a chunk's lists (every pass of the family) are enqueued right behind its launch and run
         # on the second stream beside the next chunk's, so only the last chunk's selections follow the last launch.
@@ -598,15 +598,85 @@ class SweepPlan:
                     if len(found) < 2 or any(la[2] != las[0][2] or la[4] != las[0][4] or
                                              not torch.equal(la[9], las[0][9]) for la in las):
                         continue
-                    tabs = [found[g][2][1] if g in found else None for g in (32, 64, 128)]
-                    n, blocks = las[0][2], las[0][4]
-                    for gsz, (k, j, la) in found.items():
-                        self.plan[k]["launches"][j] = ("npsweep_fused",) + tuple(la[1:])
-                    self.plan[first]["launches"].insert(0, ("npgroups", tabs, n, blocks, dt))
-                    self.ws_bytes = max(self.ws_bytes, L.mq_sweep_numpy_groups_workspace_bytes(blocks))
-                    wbytes = sum(self.weights[int(i)].numel() * 2 for i in las[0][9].cpu().tolist())
+                    ids = [int(i) for i in las[0][9].cpu().tolist()]
+                    wbytes = sum(self.weights[i].numel() * 2 for i in ids)
                     self.read_bytes -= (len(found) - 1) * wbytes
                     self.np_families += 1
+                    pos_of = {i: pos for pos, i in enumerate(self.order)}
+                    poss = [pos_of[i] for i in ids]
+                    if any(b != a + 1 for a, b in zip(poss, poss[1:])):
+                        # (layers of another dtype in between: one launch over all of them, the passes' own tables)
+                        tabs = [found[g][2][1] if g in found else None for g in (32, 64, 128)]
+                        n, blocks = las[0][2], las[0][4]
+                        for gsz, (k, j, la) in found.items():
+                            self.plan[k]["launches"][j] = ("npsweep_fused",) + tuple(la[1:])
+                        self.plan[first]["launches"].insert(0, ("npgroups", tabs, n, blocks, dt))
+                        self.ws_bytes = max(self.ws_bytes, L.mq_sweep_numpy_groups_workspace_bytes(blocks))
+                        continue
+                    # In chunks of layers, like the families of the default mode: a chunk's selections and finishing
+                    # launches (every member pass's) run beside the next chunk's launch.  A chunk is a run of
+                    # consecutive table rows, so a selection call writes straight into the pass's percentiles.
+                    nbytes = lambda pos: self.weights[self.order[pos]].numel() * 2
+                    chunk_bytes = max(int(os.environ.get("MQ_SWEEP_CHUNK_MB", "768")) << 20,
+                                      wbytes // int(os.environ.get("MQ_SWEEP_CHUNKS", "8")))
+                    chunks, cur, acc = [], [], 0
+                    for pos in poss:
+                        cur.append(pos)
+                        acc += nbytes(pos)
+                        if acc >= chunk_bytes:
+                            chunks.append(cur)
+                            cur, acc = [], 0
+                    if cur:
+                        chunks.append(cur)
+                    fused = []
+                    for chunk in chunks:
+                        n = len(chunk)
+                        rows = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[0] for pos in chunk])
+                        cols = (ctypes.c_int64 * n)(*[self.weights[self.order[pos]].shape[1] for pos in chunk])
+                        widx = torch.tensor([self.order[pos] for pos in chunk], dtype=torch.int64, device=dev)
+                        nleaves = sum(self.weights[self.order[pos]].numel() // 128 for pos in chunk)
+                        tabs, jobs, nblocks = {}, [], 0
+                        for gsz, (k, j, la) in sorted(found.items()):
+                            ps = self.plan[k]
+                            items = (_QuantItem * n)()
+                            for jj, pos in enumerate(chunk):
+                                items[jj].w = self.weights[self.order[pos]].data_ptr()
+                                items[jj].out.abs_err_dtype = _lib.F32
+                                items[jj].out.seg_mse_f32 = 2
+                                items[jj].out.seg_sse = ps["ptrs"][pos]
+                                items[jj].out.totals = ps["totals"].data_ptr() + pos * 16
+                            leaf = torch.empty(max(64, nleaves), dtype=torch.float32, device=dev)
+                            host = torch.empty(L.mq_sweep_numpy_table_bytes(n), dtype=torch.uint8)
+                            seg_len, blocks, tl, lc = (ctypes.c_int64(0) for _ in range(4))
+                            _lib.check(L.mq_sweep_numpy_prepare(items, rows, cols, n, dt, ctypes.byref(ps["cfg"]),
+                                                                leaf.data_ptr(), host.data_ptr(), host.numel(),
+                                                                ctypes.byref(seg_len), ctypes.byref(blocks),
+                                                                ctypes.byref(tl), ctypes.byref(lc)))
+                            tab = host.to(dev)
+                            rep = torch.empty(n, dtype=torch.float64, device=dev)
+                            mt = torch.empty(n, dtype=torch.float32, device=dev)
+                            sel = dict(ptrs=(ctypes.c_void_p * n)(*[ps["ptrs"][pos] for pos in chunk]),
+                                       ns=(ctypes.c_int64 * n)(*[ps["ns"][pos] for pos in chunk]), n=n,
+                                       out=self.p99_all[k][chunk[0]:chunk[0] + n])
+                            jobs.append((k, sel, (tab, n, seg_len.value, leaf, tl.value, lc.value, rep, mt)))
+                            ps["np_chunks"].append((widx, rep, mt))
+                            tabs[gsz], nblocks = tab, blocks.value
+                            self.fin_ws_bytes = max(self.fin_ws_bytes,
+                                                    L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
+                        fused.append(("npgroups", [tabs.get(g) for g in (32, 64, 128)], n, nblocks, dt, jobs,
+                                      sum(nbytes(pos) for pos in chunk)))
+                        self.ws_bytes = max(self.ws_bytes, L.mq_sweep_numpy_groups_workspace_bytes(nblocks))
+                    taken = set(poss)
+                    for gsz, (k, j, la) in found.items():   # the passes' own launches and selections give way
+                        ps = self.plan[k]
+                        ps["launches"] = [x for x in ps["launches"] if x is not la]
+                        written = [pos for pos in ps["written"] if pos not in taken]
+                        ps["written"] = written
+                        ps["sel"] = dict(ptrs=(ctypes.c_void_p * len(written))(*[ps["ptrs"][pos] for pos in written]),
+                                         ns=(ctypes.c_int64 * len(written))(*[ps["ns"][pos] for pos in written]),
+                                         n=len(written), idx=torch.tensor(written, dtype=torch.int64, device=dev),
+                                         tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
+                    self.plan[first]["launches"] = fused + self.plan[first]["launches"]
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
         self.p99_index = torch.tensor(p99_index, dtype=torch.int64, device=dev)
         self.numel_all = self.numel.repeat(npass)
@@ -698,7 +768,7 @@ class SweepPlan:
                 cfg = ps["cfg"]
                 if sampled is not None and pre is not main:
                     main.wait_event(sampled)
-                chunk_done = []
+                chunk_done, np_done = [], []
                 for la in ps["launches"]:
                     if la[0] == "multisweep":
                         # (each chunk needs the whole workspace: the partial sums of chunk i are added up before chunk
@@ -715,6 +785,10 @@ class SweepPlan:
                         t32, t64, t128 = (None if t is None else t.data_ptr() for t in la[1])
                         _lib.check(L.mq_sweep_numpy_run_groups(t32, t64, t128, la[2], la[3], la[4], ctypes.byref(cfg),
                                                                ws.data_ptr(), ws.numel(), main.cuda_stream))
+                        if len(la) > 5:   # a chunk: its passes' selections and finishing launches follow it at once
+                            done = torch.cuda.Event()
+                            done.record(main)
+                            np_done.append((la, done))
                     elif la[0] == "npsweep_fused":
                         pass      # (written by the family's npgroups launch)
                     elif la[0] == "feedsweep":
@@ -752,6 +826,15 @@ class SweepPlan:
                         _lib.check(select(beside)(job["ptrs"], job["ns"], job["n"], _lib.F32_AS_F64, self.pct,
                                                   job["out"].data_ptr(), None, sws.data_ptr(), sws.numel(),
                                                   side.cuda_stream))
+                    for j, (la, done) in enumerate(np_done):
+                        side.wait_event(done)
+                        # (beside the next chunk's launch, or -- the last chunk -- beside the launches of later passes)
+                        nxt = np_done[j + 1][0] if j + 1 < len(np_done) else None
+                        beside = (nxt[6] >= self.beside_bytes) if nxt is not None else (later or len(ps["launches"]) > len(np_done))
+                        for k2, sel2, _ in la[5]:
+                            _lib.check(select(beside)(sel2["ptrs"], sel2["ns"], sel2["n"], _lib.F32_AS_F64, self.pct,
+                                                      sel2["out"].data_ptr(), None, sws.data_ptr(), sws.numel(),
+                                                      side.cuda_stream))
                     side.wait_event(ready)
                     sel = ps["sel"]
                     if sel["n"]:
@@ -786,9 +869,15 @@ class SweepPlan:
                     # long for one beside the next pass, while these small workgroups slip in at once -- behind the
                     # selections they would pile up at the end of the step
                     with torch.cuda.stream(fin):
-                        fin.wait_event(ready)
                         fws, _ = workspace(dev, self.fin_ws_bytes)
-                        done = []
+                        for la, ev in np_done:   # the chunks' leaf sums and lists -> mse_tensor, mse_rep of their passes
+                            fin.wait_event(ev)
+                            for k2, _, (tab, n, seg_len, leaf, tl, lc, rep, mt) in la[5]:
+                                _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
+                                                                   mt.data_ptr(), rep.data_ptr(), fws.data_ptr(),
+                                                                   fws.numel(), fin.cuda_stream))
+                        fin.wait_event(ready)
+                        done = list(ps["np_chunks"])
                         # from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
                         for la in ps["launches"]:
                             if la[0] not in ("npsweep", "npsweep_fused"):
