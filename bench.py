@@ -136,7 +136,9 @@ class ModelSweep:
             fmts = [("int8", 8), ("int8_asym", 8), ("fp8_e4m3", 8), ("fp8_e3m4", 8)]
             self.passes = [(f, b, gs) for f, b in fmts for gs in SWEEP_ORDER]
         elif name == "llama8b":
-            self.passes = [("int8", 8, gs) for gs in SWEEP_ORDER]
+            # (numpy order: the per-channel pass first -- its finishing chain, one thread adding an lm_head's 64 128
+            #  chunk sums in order, then runs beside the group passes instead of behind the last launch)
+            self.passes = [("int8", 8, gs) for gs in (([None] + [g for g in SWEEP_ORDER if g]) if numpy_order else SWEEP_ORDER)]
         else:
             self.passes = [("int8", 8, None)]
         sizes = [r * c for _, (r, c) in self.layers]

@@ -320,6 +320,17 @@ class SweepPlan:
         self.select_beside = os.environ.get("MQ_SWEEP_SELECT_BESIDE", "1") != "0"   # (measurements either way)
         self.beside_bytes = int(os.environ.get("MQ_SWEEP_BESIDE_MB", "512")) << 20
         self.fin_ws_bytes = 1 << 16
+        self.fin_ws = None
+        # numpy order: every finishing call writes its tensors' mse_rep / mse_tensor into a run of these two buffers;
+        # finish() moves them to their rows with one scatter each (np_dst: flat (pass, weight) index per entry)
+        self.np_rep = torch.empty(len(self.passes) * nl, dtype=torch.float64, device=dev) if numpy_order else None
+        self.np_mt = torch.empty(len(self.passes) * nl, dtype=torch.float32, device=dev) if numpy_order else None
+        np_dst: List[int] = []
+
+        def np_slot(k, weight_ids):
+            a = len(np_dst)
+            np_dst.extend(k * nl + int(i) for i in weight_ids)
+            return self.np_rep[a:len(np_dst)], self.np_mt[a:len(np_dst)]
         self.plan = []
         if os.environ.get("MQ_SWEEP_SINGLE", "1") == "0":   # (measurements of the per-shape launches)
             single_launch = False
@@ -429,10 +440,9 @@ class SweepPlan:
                                                   ctypes.byref(lc))
                     if rc == _lib.OK:
                         widx = torch.tensor([self.order[pos] for pos in poss], dtype=torch.int64, device=dev)
+                        # (where its mse_rep / mse_tensor go is settled once the families have taken their layers)
                         launches.append(("npsweep", host.to(dev), n, seg_len.value, blocks.value, _DTYPES[dtype], leaf,
-                                         tl.value, lc.value, widx,
-                                         torch.empty(n, dtype=torch.float64, device=dev),
-                                         torch.empty(n, dtype=torch.float32, device=dev)))
+                                         tl.value, lc.value, widx, None, None))
                         self.ws_bytes = max(self.ws_bytes, L.mq_sweep_workspace_bytes(blocks.value))
                         self.fin_ws_bytes = max(self.fin_ws_bytes,
                                                 L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
@@ -628,6 +638,8 @@ class SweepPlan:
                             cur, acc = [], 0
                     if cur:
                         chunks.append(cur)
+                    # (the chunk with the largest tensor first: its finishing chain is the longest, see launch())
+                    chunks.sort(key=lambda ch: -max(nbytes(pos) for pos in ch))
                     fused = []
                     for chunk in chunks:
                         n = len(chunk)
@@ -653,13 +665,12 @@ class SweepPlan:
                                                                 ctypes.byref(seg_len), ctypes.byref(blocks),
                                                                 ctypes.byref(tl), ctypes.byref(lc)))
                             tab = host.to(dev)
-                            rep = torch.empty(n, dtype=torch.float64, device=dev)
-                            mt = torch.empty(n, dtype=torch.float32, device=dev)
+                            rep, mt = np_slot(k, [self.order[pos] for pos in chunk])
                             sel = dict(ptrs=(ctypes.c_void_p * n)(*[ps["ptrs"][pos] for pos in chunk]),
                                        ns=(ctypes.c_int64 * n)(*[ps["ns"][pos] for pos in chunk]), n=n,
                                        out=self.p99_all[k][chunk[0]:chunk[0] + n])
                             jobs.append((k, sel, (tab, n, seg_len.value, leaf, tl.value, lc.value, rep, mt)))
-                            ps["np_chunks"].append((widx, rep, mt))
+                            ps["np_chunks"].append((widx, rep, mt))   # (kept for inspection: finish() scatters them)
                             tabs[gsz], nblocks = tab, blocks.value
                             self.fin_ws_bytes = max(self.fin_ws_bytes,
                                                     L.mq_sweep_numpy_finish_workspace_bytes(tl.value, lc.value))
@@ -678,6 +689,11 @@ class SweepPlan:
                                          tmp=torch.zeros(max(1, len(written)), dtype=torch.float64, device=dev))
                     self.plan[first]["launches"] = fused + self.plan[first]["launches"]
         self.side_ws_bytes = max(self.side_ws_bytes, self.L.mq_percentile_batch_workspace_bytes(min(nl, 64)))
+        for k, ps in enumerate(self.plan):
+            for j, la in enumerate(ps["launches"]):
+                if la[0] in ("npsweep", "npsweep_fused"):
+                    ps["launches"][j] = tuple(la[:10]) + np_slot(k, la[9].cpu().tolist())
+        self.np_dst = torch.tensor(np_dst, dtype=torch.int64, device=dev) if np_dst else None
         self.p99_index = torch.tensor(p99_index, dtype=torch.int64, device=dev)
         self.numel_all = self.numel.repeat(npass)
         # row (k, order[pos]) of the records <- source k * nl + pos
@@ -736,12 +752,19 @@ class SweepPlan:
             if side is None:
                 side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)      # (the previous consumers of the plan's buffers are ordered on `main`)
-            fin = main
+            # numpy order: the finishing launches of pass k on stream k mod 4 of their own (a tensor's float32 chunk sums
+            # are added by ONE thread in numpy's order -- 0.3 ms for the 64 128 chunks of an lm_head -- and the passes'
+            # chains are independent of each other)
+            fins = [main] * 4
             if self.numpy_order and overlap:
-                fin = _side_streams.get((dev.index, "fin"))
-                if fin is None:
-                    fin = _side_streams[(dev.index, "fin")] = torch.cuda.Stream(device=dev)
-                fin.wait_stream(main)
+                for j in range(4):
+                    f = _side_streams.get((dev.index, "fin", j))
+                    if f is None:
+                        f = _side_streams[(dev.index, "fin", j)] = torch.cuda.Stream(device=dev)
+                    f.wait_stream(main)
+                    fins[j] = f
+            if self.numpy_order and (self.fin_ws is None or self.fin_ws[0].numel() < self.fin_ws_bytes):
+                self.fin_ws = [torch.empty(self.fin_ws_bytes, dtype=torch.uint8, device=dev) for _ in range(4)]
             ws, _ = workspace(dev, self.ws_bytes)
             # the sampling launches of pass k (fed lists: samples -> brackets) run on a stream of their own beside the
             # launches of pass k - 1 (behind the selections on the second stream they would hold up pass k)
@@ -868,16 +891,17 @@ class SweepPlan:
                     # THIRD stream: the selections' histogram kernels want a whole compute unit per workgroup and wait
                     # long for one beside the next pass, while these small workgroups slip in at once -- behind the
                     # selections they would pile up at the end of the step
+                    for la, ev in np_done:   # the chunks' leaf sums and lists -> mse_tensor, mse_rep of their passes
+                        for k2, _, (tab, n, seg_len, leaf, tl, lc, rep, mt) in la[5]:
+                            f2, fws2 = fins[k2 % 4], self.fin_ws[k2 % 4]
+                            f2.wait_event(ev)
+                            _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
+                                                               mt.data_ptr(), rep.data_ptr(), fws2.data_ptr(),
+                                                               fws2.numel(), f2.cuda_stream))
+                    fin, fws = fins[k % 4], self.fin_ws[k % 4]
                     with torch.cuda.stream(fin):
-                        fws, _ = workspace(dev, self.fin_ws_bytes)
-                        for la, ev in np_done:   # the chunks' leaf sums and lists -> mse_tensor, mse_rep of their passes
-                            fin.wait_event(ev)
-                            for k2, _, (tab, n, seg_len, leaf, tl, lc, rep, mt) in la[5]:
-                                _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
-                                                                   mt.data_ptr(), rep.data_ptr(), fws.data_ptr(),
-                                                                   fws.numel(), fin.cuda_stream))
                         fin.wait_event(ready)
-                        done = list(ps["np_chunks"])
+                        done = []
                         # from the launch's leaf sums and lists (the layers of a numpy-order launch) ...
                         for la in ps["launches"]:
                             if la[0] not in ("npsweep", "npsweep_fused"):
@@ -886,7 +910,6 @@ class SweepPlan:
                             _lib.check(L.mq_sweep_numpy_finish(tab.data_ptr(), n, seg_len, leaf.data_ptr(), tl, lc,
                                                                mt.data_ptr(), rep.data_ptr(), fws.data_ptr(),
                                                                fws.numel(), fin.cuda_stream))
-                            done.append((widx, rep, mt))
                         # ... or layer by layer (shapes the numpy-order launch does not take)
                         slow = ps["slow_pos"]
                         if slow:
@@ -901,17 +924,23 @@ class SweepPlan:
                         for widx, rep, mt in done:
                             self.records[k][:, 3].index_copy_(0, widx, rep)
                             self.mse_tensor[k].index_copy_(0, widx, mt.double())
-            self._pending = (main, side, fin)
+            self._pending = (main, side, fins)
 
     @torch.no_grad()
     def finish(self) -> torch.Tensor:
         """Joins the second stream into the one launch() ran on and returns the records (ordered on that stream)."""
-        main, side, fin = self._pending
+        main, side, fins = self._pending
         self._pending = None
         if side is not main:
             main.wait_stream(side)
-        if fin is not main:
-            main.wait_stream(fin)
+        for fin in fins:
+            if fin is not main:
+                main.wait_stream(fin)
+        if self.numpy_order and self.np_dst is not None:
+            # mse_rep and mse_tensor of every finishing call of the run to their rows: one scatter each
+            m = self.np_dst.numel()
+            self.records.view(-1, len(RECORD_FIELDS))[:, 3].index_copy_(0, self.np_dst, self.np_rep[:m])
+            self.mse_tensor.view(-1).index_copy_(0, self.np_dst, self.np_mt[:m].double())
         return self.records
 
 

@@ -6,9 +6,10 @@ import torch
 import bench
 from quantization_amd import report
 dev = torch.device("cuda", 0)
-worlds = [int(a) for a in sys.argv[1:]] or [1, 8]
+NP = "--numpy" in sys.argv
+worlds = [int(a) for a in sys.argv[1:] if a != "--numpy"] or [1, 8]
 for world in worlds:
-    wl = bench.ModelSweep("llama8b", dev, 0, world, "normal")
+    wl = bench.ModelSweep("llama8b", dev, 0, world, "normal", numpy_order=NP)
     marks = []
     orig = wl.plan.launch
     def launch(overlap=True, _o=orig):
