@@ -364,6 +364,14 @@ int mq_sweep_multi_prepare(const mq_multi_item* items, const int64_t* rows, int6
                            int64_t* total_blocks);
 int mq_sweep_multi_run(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
                        const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes, void* hip_stream);
+/* The two halves of mq_sweep_multi_run, for callers that keep the small totals launch off the stream of the statistics
+ * launches (then every launch in flight needs a workspace of its own): _launch enqueues the statistics kernel only,
+ * _finalize adds its workgroups' partial sums into the tensors' totals, on any stream ordered behind that launch. */
+int mq_sweep_multi_launch(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
+                          const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes,
+                          void* hip_stream);
+int mq_sweep_multi_finalize(const void* table_dev, int32_t count, int64_t total_blocks, void* workspace,
+                            size_t workspace_bytes, void* hip_stream);
 
 /*
  * mq_quantize_batch plus p99[i] = np.percentile(abs_err_i, pct) (float32, method 'linear': the P99 of

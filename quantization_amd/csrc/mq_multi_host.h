@@ -53,9 +53,40 @@ extern "C" int mq_sweep_multi_prepare(const mq_multi_item* items, const int64_t*
   return MQ_OK;
 }
 
+static int sweep_multi_launch(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
+                              const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes,
+                              void* hip_stream, bool finalize);
 extern "C" int mq_sweep_multi_run(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
                                   const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes,
                                   void* hip_stream) {
+  return sweep_multi_launch(table_dev, count, cols, total_blocks, w_dtype, cfg, mask, workspace, workspace_bytes, hip_stream,
+                            true);
+}
+// The two halves of mq_sweep_multi_run for callers that keep the small totals launch off the stream of the big ones
+// (a workspace of its own per launch in flight): _launch enqueues the statistics kernel only, _finalize adds the
+// workgroups' partial sums into the tensors' totals -- on any stream that is ordered behind the launch.
+extern "C" int mq_sweep_multi_launch(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks,
+                                     int32_t w_dtype, const mq_quant_cfg* cfg, uint32_t mask, void* workspace,
+                                     size_t workspace_bytes, void* hip_stream) {
+  return sweep_multi_launch(table_dev, count, cols, total_blocks, w_dtype, cfg, mask, workspace, workspace_bytes, hip_stream,
+                            false);
+}
+extern "C" int mq_sweep_multi_finalize(const void* table_dev, int32_t count, int64_t total_blocks, void* workspace,
+                                       size_t workspace_bytes, void* hip_stream) {
+  if (!table_dev || count < 1 || total_blocks < 1) return MQ_ERR_ARG;
+  if (!workspace || workspace_bytes < mq_sweep_multi_workspace_bytes(total_blocks)) return MQ_ERR_WORKSPACE;
+  if (!aligned(workspace, 16) || !aligned(table_dev, 8)) return MQ_ERR_ALIGN;
+  QuantBatch b = {};
+  b.multi = static_cast<const MultiItem*>(table_dev);
+  b.multi_count = count;
+  b.sweep_partials = static_cast<double*>(workspace);
+  hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)count, 4), dim3(256), 0, static_cast<hipStream_t>(hip_stream), b);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+static int sweep_multi_launch(const void* table_dev, int32_t count, int64_t cols, int64_t total_blocks, int32_t w_dtype,
+                              const mq_quant_cfg* cfg, uint32_t mask, void* workspace, size_t workspace_bytes,
+                              void* hip_stream, bool finalize) {
   if (!table_dev || count < 1 || total_blocks < 1 || total_blocks > 0x7fffffffll || !(mask & 15u) || (mask & ~15u))
     return MQ_ERR_ARG;
   if (int rc = sweep_check_cfg(w_dtype, cfg)) return rc;
@@ -98,7 +129,9 @@ extern "C" int mq_sweep_multi_run(const void* table_dev, int32_t count, int64_t 
   if (rc) return rc;
   MQ_HIP(hipGetLastError());
   if (prof_on) MQ_HIP(hipEventRecord(prof_e1, st));
-  hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)count, 4), dim3(256), 0, st, b);
-  MQ_HIP(hipGetLastError());
+  if (finalize) {
+    hipLaunchKernelGGL(k_finalize_multi, dim3((unsigned)count, 4), dim3(256), 0, st, b);
+    MQ_HIP(hipGetLastError());
+  }
   return MQ_OK;
 }

@@ -240,6 +240,10 @@ def bind_batch():
         L_.mq_sweep_multi_prepare.restype = ctypes.c_int
         L_.mq_sweep_multi_prepare.argtypes = [ctypes.POINTER(_MultiItem), ctypes.POINTER(i64), i64, i32, i32,
                                               ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, ctypes.POINTER(i64)]
+        L_.mq_sweep_multi_launch.restype = ctypes.c_int
+        L_.mq_sweep_multi_launch.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, vp]
+        L_.mq_sweep_multi_finalize.restype = ctypes.c_int
+        L_.mq_sweep_multi_finalize.argtypes = [vp, i32, i64, vp, sz, vp]
         L_.mq_sweep_multi_run.restype = ctypes.c_int
         L_.mq_sweep_multi_run.argtypes = [vp, i32, i64, i64, i32, ctypes.POINTER(_lib.QuantCfg), ctypes.c_uint32, vp, sz, vp]
         L_.mq_sweep_table_bytes.restype = sz

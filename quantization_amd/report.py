@@ -316,6 +316,7 @@ class SweepPlan:
         self.totals_all = torch.zeros(npass, nl, 2, dtype=torch.float64, device=dev)
         self.table = None     # set_table(): the records go straight into a table over more layers than this plan holds
         self.ws_bytes = 0
+        self.multi_ws_bytes = 0
         self.side_ws_bytes = 0
         self.select_beside = os.environ.get("MQ_SWEEP_SELECT_BESIDE", "1") != "0"   # (measurements either way)
         self.beside_bytes = int(os.environ.get("MQ_SWEEP_BESIDE_MB", "512")) << 20
@@ -585,7 +586,12 @@ class SweepPlan:
                     p99_used += m
                     first["launches"].append(("multisweep", host.to(dev), n, C, blocks.value, _DTYPES[dtype], mask, job))
                     self.side_ws_bytes = max(self.side_ws_bytes, L.mq_percentile_batch_workspace_bytes(min(m, 64)))
-                    self.ws_bytes = max(self.ws_bytes, L.mq_sweep_multi_workspace_bytes(blocks.value))
+                    # (a workspace of its own per chunk: the totals launch of chunk i runs on the second stream, beside
+                    #  the statistics launch of chunk i + 1)
+                    job["ws_off"] = self.multi_ws_bytes
+                    job["ws_len"] = L.mq_sweep_multi_workspace_bytes(blocks.value)
+                    self.multi_ws_bytes += (job["ws_len"] + 255) // 256 * 256
+                    self.ws_bytes = max(self.ws_bytes, self.multi_ws_bytes)
         # numpy order: the passes of one format with groups of 32 / 64 / 128 share ONE read too (mq_sweep_numpy_run_groups:
         # their launch tables list the same tensors in the same order); each pass keeps its own finishing launches
         self.np_families = 0
@@ -796,8 +802,14 @@ class SweepPlan:
                     if la[0] == "multisweep":
                         # (each chunk needs the whole workspace: the partial sums of chunk i are added up before chunk
                         #  i + 1 starts, on this stream)
-                        _lib.check(L.mq_sweep_multi_run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg),
-                                                        la[6], ws.data_ptr(), ws.numel(), main.cuda_stream))
+                        job = la[7]
+                        # (the totals launch of a chunk on the second stream, beside the next statistics launch -- but
+                        #  behind the step's last launch there is nothing to run beside)
+                        last = la is ps["launches"][-1] and not any(ps2["launches"] for ps2 in self.plan[k + 1:])
+                        job["split"] = side is not main and not last and os.environ.get("MQ_SWEEP_SPLIT_FINALIZE", "1") != "0"
+                        run = L.mq_sweep_multi_launch if job["split"] else L.mq_sweep_multi_run
+                        _lib.check(run(la[1].data_ptr(), la[2], la[3], la[4], la[5], ctypes.byref(cfg), la[6],
+                                       ws.data_ptr() + job["ws_off"], job["ws_len"], main.cuda_stream))
                         done = torch.cuda.Event()
                         done.record(main)
                         chunk_done.append((la, done))
@@ -843,6 +855,9 @@ class SweepPlan:
                     for j, (la, done) in enumerate(chunk_done):
                         side.wait_event(done)
                         job = la[7]
+                        if job["split"]:   # the chunk's totals from its workgroups' partial sums
+                            _lib.check(L.mq_sweep_multi_finalize(la[1].data_ptr(), la[2], la[4], ws.data_ptr() + job["ws_off"],
+                                                                 job["ws_len"], side.cuda_stream))
                         # (beside the NEXT launch; a short one is over before the slower small workgroups are)
                         nxt = chunk_done[j + 1][0] if j + 1 < len(chunk_done) else None
                         beside = nxt is not None and nxt[7]["bytes"] >= self.beside_bytes
