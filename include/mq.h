@@ -127,6 +127,11 @@ int mq_profile_end(double* total_ms, int64_t* launches);
  * rounded integer differs, pairs with |v / scale| >= 2^-4 whose float16 bits differ; the last two must be 0.
  */
 int mq_selfcheck_div16(uint64_t* counts, void* hip_stream);
+/* The same for the division with a SHARED power of two: 2^(k - j), j = 0, 1 or 2, in place of the scale's own 2^k --
+ * what the several-groupings kernel uses for a group inside a row whose scale is up to 4 x larger (one scaled copy of
+ * the weights serves every grouping).  counts[2] then counts differing bits for |v / s| >= 2^(j - 4); counts[1] must
+ * be 0 as above.  No counterpart in the reference. */
+int mq_selfcheck_div16_shared(uint64_t* counts, int32_t j, void* hip_stream);
 
 /*
  * Device self-check (no counterpart in the reference): does the hardware's packed float32 -> fp8 e4m3 conversion

@@ -128,10 +128,14 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
       rowred = stats_op<FMT>(rowred, red[r]);
     }
     SegP sp0;
+    // integer formats: the row's power of two serves every grouping of the row (pk_div_params): v P once per word
+    int kb = MQ_PK_OWN;
     if (on0) {
       sp0 = row_params(rowred);
       seen_slow = seen_slow || sp0.slow;
+      if constexpr (!MQ_IS_LUT(FMT)) kb = (sp0.slow || (b.multi_mask & 0x80000000u)) ? MQ_PK_OWN : sp0.pk_k;
     }
+    const bool share = kb != MQ_PK_OWN;  // (uniform over the row)
     double rs0 = 0.0;
     // the lists' entries of this row: list + row * entries per row (64-bit once per row, 32-bit offsets below)
     float* const l1 = list1 ? list1 + row * runs : nullptr;
@@ -142,9 +146,26 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
       const int run = (r * WPR + sub) * 64 + lane;
       const bool valid = whole || run < runs;
       const u32x4* v = &raw[4 * r];
+      u32x4 pre[4];
+      if (share) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pre[k][i] = as_u32(as_h2(v[k][i]) * as_h2(sp0.pk_p));
+      }
+      // one grouping of the run: on the shared words when every lane's segment took the row's power of two
+      auto vectors = [&](const SegP& sp, bool lane_ok, double& s, double& ab) __attribute__((always_inline)) {
+        if constexpr (!MQ_IS_LUT(FMT)) {
+          if (share && __builtin_amdgcn_ballot_w64(lane_ok && !sp.pk_shared) == 0ull) {
+            stats_vectors<FMT, 4, false, true>(p, v, sp, s, ab, nullptr, pre);
+            return;
+          }
+        }
+        stats_vectors<FMT, 4>(p, v, sp, s, ab);
+      };
       if (on0 && !sp0.slow) {
         double s, ab;
-        stats_vectors<FMT, 4>(p, v, sp0, s, ab);
+        vectors(sp0, true, s, ab);
         rs0 += s;
         abs0 += ab;
       }
@@ -152,22 +173,22 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
       const uint32_t r2 = stats_op<FMT>(r1, dpp<DPP_XOR1>(r1));
       const uint32_t r3 = stats_op<FMT>(r2, dpp<DPP_XOR2>(r2));
       if (on1) {
-        const SegP sp = stats_params<FMT>(r1, p);
+        const SegP sp = stats_params<FMT>(r1, p, kb);
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
-        stats_vectors<FMT, 4>(p, v, sp, s, ab);
+        vectors(sp, take, s, ab);
         s = take ? s : 0.0;
         sse1 += s;
         abs1 += take ? ab : 0.0;
         if (l1 && take) l1[run] = (float)(s * (1.0 / 32.0));
       }
       if (on2) {
-        const SegP sp = stats_params<FMT>(r2, p);
+        const SegP sp = stats_params<FMT>(r2, p, kb);
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
-        stats_vectors<FMT, 4>(p, v, sp, s, ab);
+        vectors(sp, take, s, ab);
         s = take ? s : 0.0;
         sse2 += s;
         abs2 += take ? ab : 0.0;
@@ -175,11 +196,11 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
         if (l2 && take && (lane & 1) == 0) l2[run >> 1] = (float)(s * (1.0 / 64.0));
       }
       if (on3) {
-        const SegP sp = stats_params<FMT>(r3, p);
+        const SegP sp = stats_params<FMT>(r3, p, kb);
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
-        stats_vectors<FMT, 4>(p, v, sp, s, ab);
+        vectors(sp, take, s, ab);
         s = take ? s : 0.0;
         sse3 += s;
         abs3 += take ? ab : 0.0;

@@ -227,6 +227,8 @@ struct SegP {
   // statistics-only integer formats (div_pk16): P = 2^k with s * P in [1, 2), s * P and RN16(1 / (s * P)), each
   // as a pair of equal float16 halves
   uint32_t pk_p, pk_s, pk_r;
+  int pk_k;        // log2 of P
+  bool pk_shared;  // P is the power of two the caller offered (a larger segment's), not the segment's own
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -703,8 +705,20 @@ __device__ __forceinline__ uint32_t div_pk_abs(uint32_t vw, const SegP& sp) {
 // always (below 2^-4 the remainder may be inexact and q1 a few ulp off: both round to 0) -- enumerated on the
 // CPU by tests/tools/div16_exhaustive.c and on the device by mq_selfcheck_div16.  That is all the integer formats
 // need from the quotient.  The sign of a zero quotient follows v.
-__device__ __forceinline__ void pk_div_params(SegP& sp) {
-  const int k = 1 - __builtin_amdgcn_frexp_expf(sp.sf);  // sf = m 2^e, m in [0.5, 1): s 2^k in [1, 2)
+//
+// A SHARED P.  Segments that nest (a group inside a row) can divide the same v' = v P_b, P_b = 2^k_b the power of two
+// of the LARGER segment's scale: with j = k - k_b in {0, 1, 2} every operand above is the own-P operand times 2^-j
+// (v', s', the remainder) or 2^j (r = RN16(1 / s'): rounding commutes with a power of two), so q0 is unchanged and q1
+// has the same bits wherever the smaller remainder is still exact -- |v / s| >= 2^(j - 4) <= 1/4 -- and below that
+// both quotients lie under 1/2 and round to 0: rint(q1) = rint(h(v / s)) as before.  mq_selfcheck_div16_shared
+// enumerates it on the device for j = 1, 2 like mq_selfcheck_div16 does for j = 0.  k_base: the offered exponent
+// (MQ_PK_OWN: none); taken when 0 <= k - k_base <= 2 (sp.pk_shared), the own one otherwise.
+#define MQ_PK_OWN (-100000)
+__device__ __forceinline__ void pk_div_params(SegP& sp, int k_base = MQ_PK_OWN) {
+  const int k_own = 1 - __builtin_amdgcn_frexp_expf(sp.sf);  // sf = m 2^e, m in [0.5, 1): s 2^k in [1, 2)
+  sp.pk_shared = (unsigned)(k_own - k_base) <= 2u;
+  const int k = sp.pk_shared ? k_base : k_own;
+  sp.pk_k = k;
   const float s1 = __builtin_ldexpf(sp.sf, k);
   sp.pk_p = dup16(h_bits((half_t)__builtin_ldexpf(1.0f, k)));  // (k <= 15 is the caller's test: s >= 2^-15)
   sp.pk_s = dup16(h_bits((half_t)s1));
@@ -712,11 +726,14 @@ __device__ __forceinline__ void pk_div_params(SegP& sp) {
   // rounds to the same float16 (same test program)
   sp.pk_r = dup16(h_bits((half_t)__builtin_amdgcn_rcpf(s1)));
 }
-__device__ __forceinline__ h16x2 div_pk16(uint32_t vw, const SegP& sp) {
-  const h16x2 v1 = as_h2(vw) * as_h2(sp.pk_p);
+__device__ __forceinline__ h16x2 div_pk16_pre(uint32_t v1w, const SegP& sp) {  // v1w: v P, both halves
+  const h16x2 v1 = as_h2(v1w);
   const h16x2 q0 = v1 * as_h2(sp.pk_r);
   const h16x2 rem = __builtin_elementwise_fma(-q0, as_h2(sp.pk_s), v1);
   return __builtin_elementwise_fma(rem, as_h2(sp.pk_r), q0);
+}
+__device__ __forceinline__ h16x2 div_pk16(uint32_t vw, const SegP& sp) {
+  return div_pk16_pre(as_u32(as_h2(vw) * as_h2(sp.pk_p)), sp);
 }
 // |nearest table value| for the two float16 magnitudes |x| in xw (sign bits clear), for a table WITHOUT
 // subnormals; vw: the weights (x has their sign: a tie goes to the smaller VALUE, i.e. down for positive and up in
@@ -738,9 +755,10 @@ __device__ __forceinline__ uint32_t lut_round_mag_pk(uint32_t xw, uint32_t vw, c
 // PK16: the integer formats divide in packed float16 (div_pk16; sp must carry pk_p / pk_s / pk_r: stats_params).
 // SQ: the 8 float32 squared errors (exact: a float16 error squared has 22 significant bits) also go to sq[0..7], in
 // element order, for the list entries summed in numpy's order (numpy_entry).
-template <int FMT, bool PK16 = false, bool SQ = false>
+// PRE (integer formats with PK16): pre holds the words of raw times sp's P already (a shared P, see pk_div_params).
+template <int FMT, bool PK16 = false, bool SQ = false, bool PRE = false>
 __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 raw, const SegP& sp, float& sse,
-                                             float& sabs, float* sq = nullptr) {
+                                             float& sabs, float* sq = nullptr, const u32x4 pre = u32x4{0, 0, 0, 0}) {
   const h16x2 s2 = as_h2(dup16(h_bits(sp.s)));
   const h16x2 magic = as_h2(0x66006600u);  // 1536
   float q = 0.f, q1 = 0.f;
@@ -748,7 +766,8 @@ __device__ __forceinline__ void quant8_stats(const QuantParams& p, const u32x4 r
   for (int k = 0; k < 4; ++k) {
     const uint32_t vw = raw[k];
     h16x2 x, e;
-    if constexpr (FMT != MQ_LUT_FP) x = (PK16 && !MQ_IS_LUT(FMT)) ? div_pk16(vw, sp) : div_pk(vw, sp);
+    if constexpr (PRE && PK16 && !MQ_IS_LUT(FMT)) x = div_pk16_pre(pre[k], sp);
+    else if constexpr (FMT != MQ_LUT_FP) x = (PK16 && !MQ_IS_LUT(FMT)) ? div_pk16(vw, sp) : div_pk(vw, sp);
     if constexpr (FMT == MQ_INT_SYM) {
       e = as_h2(vw) - ((x + magic) - magic) * s2;
     } else if constexpr (FMT == MQ_INT_ASYM) {
@@ -1367,15 +1386,16 @@ __device__ __forceinline__ uint32_t stats_op(uint32_t a, uint32_t b) {
 }
 // params_absmax / params_minmax with the common case in few instructions: h(a / qmax) by the reciprocal multiply
 // in mixed precision when the host has verified it for this qmax, the clamp as v_max / v_min_f16.
+// k_base: a shared power of two offered to the packed division (pk_div_params).
 template <int FMT>
-__device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p) {
+__device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p, int k_base = MQ_PK_OWN) {
   if (!p.qmax_recip_ok) {
     SegP sp;
     if constexpr (FMT == MQ_INT_ASYM) sp = params_minmax(red, p);
     else sp = params_absmax(red, p);
     if constexpr (!MQ_IS_LUT(FMT)) {
       sp.slow = sp.slow || sp.sf < 0x1p-15f;
-      pk_div_params(sp);
+      pk_div_params(sp, k_base);
     }
     return sp;
   }
@@ -1398,7 +1418,7 @@ __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p)
     sp.slow = !(big * sp.r < 500.0f) || !((float)h_from_bits(range) < 65504.0f) || s0 > hi || !(s0 == s0) ||
               (float)rmin > 0.f || (float)rmax < 0.f || sp.sf < 0x1p-15f;
     if (sp.slow) { sp = params_minmax(red, p); sp.slow = true; }
-    else pk_div_params(sp);
+    else pk_div_params(sp, k_base);
   } else {
     const float q0 = mix_mul_lo(red, p.rqmax);
     const half_t s0 = (half_t)__builtin_fmaf(mix_rem_lo(q0, p.qmax, red), p.rqmax, q0);
@@ -1408,14 +1428,14 @@ __device__ __forceinline__ SegP stats_params(uint32_t red, const QuantParams& p)
     // range of the packed division
     sp.slow = red >= 0x7c00u || s0 > hi || sp.sf < 0x1p-15f;
     if (sp.slow) { sp = params_absmax(red, p); sp.slow = true; }
-    else if constexpr (!MQ_IS_LUT(FMT)) pk_div_params(sp);
+    else if constexpr (!MQ_IS_LUT(FMT)) pk_div_params(sp, k_base);
   }
   return sp;
 }
 // NV vectors of one segment held by this lane (fast path) -> float64 sum of squared errors, sum of |error|
-template <int FMT, int NV, bool SQ = false>
+template <int FMT, int NV, bool SQ = false, bool PRE = false>
 __device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4* raw, const SegP& sp, double& sse,
-                                              double& sabs, float (*sq)[8] = nullptr) {
+                                              double& sabs, float (*sq)[8] = nullptr, const u32x4* pre = nullptr) {
   // float32 within two vectors (squares: 8 dot steps + 1 add) resp. four vectors (|error|), float64 above
   sse = 0.0;
   sabs = 0.0;
@@ -1423,6 +1443,7 @@ __device__ __forceinline__ void stats_vectors(const QuantParams& p, const u32x4*
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     if constexpr (SQ) quant8_stats<FMT, true, true>(p, raw[j], sp, q, ab, sq[j]);
+    else if constexpr (PRE) quant8_stats<FMT, true, false, true>(p, raw[j], sp, q, ab, nullptr, pre[j]);
     else quant8_stats<FMT, true>(p, raw[j], sp, q, ab);
     if ((j & 1) == 1 || j == NV - 1) { sse += (double)q; q = 0.f; }
     if ((j & 3) == 3 || j == NV - 1) { sabs += (double)ab; ab = 0.f; }
@@ -2808,13 +2829,17 @@ extern "C" size_t mq_quantize_batch_workspace_bytes(int32_t count, int64_t, int6
 // div_pk16 (with this device's v_rcp_f32 in pk_div_params) against the float32 division sequence of the general
 // kernels (div_f: equal to the IEEE quotient on this domain, tests/tools/div_exhaustive.c).
 // counts[0] pairs checked, [1] pairs whose rint differs, [2] pairs with |v / s| >= 2^-4 whose bits differ.
-__global__ __launch_bounds__(256) void k_selfcheck_div16(unsigned long long* counts) {
+// j > 0: with the shared power of two 2^(k - j) in place of the scale's own 2^k (pk_div_params); the bits are then
+// compared for |v / s| >= 2^(j - 4).
+__global__ __launch_bounds__(256) void k_selfcheck_div16(unsigned long long* counts, int j) {
   const uint32_t sb = 0x0200u + blockIdx.x;
   SegP sp;
   finish_params(sp, h_from_bits(sb));
   sp.zp = (half_t)0;
   sp.slow = false;
   pk_div_params(sp);
+  if (j > 0) pk_div_params(sp, sp.pk_k - j);
+  const float exact_from = __builtin_ldexpf(0.0625f, j);
   unsigned long long n = 0, bad_rint = 0, bad_bits = 0;
   for (uint32_t vb = threadIdx.x; vb < 0x7c00u; vb += blockDim.x) {
     const half_t v = h_from_bits(vb);
@@ -2824,7 +2849,7 @@ __global__ __launch_bounds__(256) void k_selfcheck_div16(unsigned long long* cou
     n += 2;
     const float w = (float)want;
     bad_rint += (__builtin_rintf((float)got[0]) != __builtin_rintf(w)) + (__builtin_rintf((float)got[1]) != __builtin_rintf(-w));
-    if (w >= 0.0625f) bad_bits += (h_bits(got[0]) != h_bits(want)) + (h_bits(got[1]) != (h_bits(want) | 0x8000u));
+    if (w >= exact_from) bad_bits += (h_bits(got[0]) != h_bits(want)) + (h_bits(got[1]) != (h_bits(want) | 0x8000u));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -2840,7 +2865,17 @@ extern "C" int mq_selfcheck_div16(uint64_t* counts_device, void* hip_stream) {
   hipStream_t st = static_cast<hipStream_t>(hip_stream);
   MQ_HIP(hipMemsetAsync(counts_device, 0, 3 * sizeof(uint64_t), st));
   hipLaunchKernelGGL(k_selfcheck_div16, dim3(0x70E2u - 0x0200u + 1u), dim3(256), 0, st,
-                     reinterpret_cast<unsigned long long*>(counts_device));
+                     reinterpret_cast<unsigned long long*>(counts_device), 0);
+  MQ_HIP(hipGetLastError());
+  return MQ_OK;
+}
+extern "C" int mq_selfcheck_div16_shared(uint64_t* counts_device, int32_t j, void* hip_stream) {
+  if (!counts_device || j < 0 || j > 2) return MQ_ERR_ARG;
+  if (reinterpret_cast<uintptr_t>(counts_device) % 8) return MQ_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  MQ_HIP(hipMemsetAsync(counts_device, 0, 3 * sizeof(uint64_t), st));
+  hipLaunchKernelGGL(k_selfcheck_div16, dim3(0x70E2u - 0x0200u + 1u), dim3(256), 0, st,
+                     reinterpret_cast<unsigned long long*>(counts_device), (int)j);
   MQ_HIP(hipGetLastError());
   return MQ_OK;
 }

@@ -9,9 +9,12 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("args", [(), ("4", "452")], ids=["integer formats", "scaled variant (tables)"])
+@pytest.mark.parametrize("args", [(), ("-1",), ("-2",), ("4", "452")],
+                         ids=["integer formats", "shared power of two, 2x", "shared power of two, 4x", "scaled variant (tables)"])
 def test_packed_float16_division_is_exact(tmp_path, args):
     """(): div_pk16 as the integer formats use it (s' in [1, 2), |v / s| <= 600, bits exact from 2^-4 up).
+    ("-1",), ("-2",): a row's power of two shared by a group whose scale is up to 2 x / 4 x smaller (pk_div_params'
+    k_base): s' in [1/2, 1) / [1/4, 1/2), bits exact from 2^-3 / 2^-2 up, rint equal everywhere.
     ("4", "452"): s' in [16, 32) -- exact from 2^-8 up, which would cover every table's smallest midpoint; not
     used by the kernels (it saves under 5 issue cycles per pair over the mixed-precision division), kept as the
     record of that result."""

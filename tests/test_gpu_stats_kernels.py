@@ -187,6 +187,22 @@ def test_packed_division_selfcheck_on_device():
     assert pairs > 1_200_000_000 and bad_rint == 0 and bad_bits == 0, (pairs, bad_rint, bad_bits)
 
 
+@pytest.mark.parametrize("j", [0, 1, 2])
+def test_packed_division_with_a_shared_power_of_two_selfcheck_on_device(j):
+    """mq_selfcheck_div16_shared: the same enumeration with the power of two of a scale up to 4 x larger in place of
+    the scale's own (what the several-groupings kernel offers the groups of a row): rint never differs, the bits
+    never differ from |v / s| = 2^(j - 4) on."""
+    import ctypes
+    from quantization_amd import _lib
+    L = _lib.lib()
+    L.mq_selfcheck_div16_shared.restype = ctypes.c_int
+    L.mq_selfcheck_div16_shared.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    counts = torch.full((3,), -1, dtype=torch.int64, device="cuda")
+    _lib.check(L.mq_selfcheck_div16_shared(counts.data_ptr(), j, torch.cuda.current_stream().cuda_stream))
+    pairs, bad_rint, bad_bits = counts.cpu().tolist()
+    assert pairs > 1_200_000_000 and bad_rint == 0 and bad_bits == 0, (j, pairs, bad_rint, bad_bits)
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("fmt", FORMATS, ids=[f[0] for f in FORMATS])
 def test_numpy_order_list_entries_are_bit_exact(oracle, fmt, dt):

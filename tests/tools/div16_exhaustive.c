@@ -50,7 +50,9 @@ static inline float fma16(float a, float b, float c, long* inexact) {
   return hr(round_odd_f32(s));
 }
 
-/* argv: J QMAX (defaults 0 600).  J > 0 is the table formats' variant: s' = s 2^k 2^J lies in [2^J, 2^(J+1)) (the
+/* argv: J QMAX (defaults 0 600).  J < 0 (-1, -2) is the SHARED power of two of the several-groupings kernel: a group
+ * inside a row divides v 2^(k+J), the row's prescaled weights, so s' = s 2^(k+J) lies in [2^J, 2^(J+1)) and the bits are
+ * exact from T = 2^(-4-J) <= 1/4 up (rint equal everywhere: what the integer formats need).  J > 0 is the table formats' variant: s' = s 2^k 2^J lies in [2^J, 2^(J+1)) (the
  * weight takes two power-of-two factors, P1 P2 = 2^(k+J), since 2^(k+J) itself may exceed float16), which moves the
  * exactness threshold down to T = 2^(-4-J); QMAX bounds the quotient.  Sixth number printed: quotients below T whose
  * q1 is not below T as well (must be 0: then every table whose smallest 0 / entry midpoint is >= T rounds q1 and
@@ -74,7 +76,8 @@ int main(int argc, char** argv) {
     int e;
     frexpf(s, &e);
     const int k = 1 - e;
-    const int k1 = (k + J + 1) / 2, k2 = k + J - k1;      /* both factors are float16 numbers: k + J <= 15 + J */
+    /* both factors are float16 numbers: k + J <= 15 + J; for J <= 0 there is ONE factor, as in the kernels */
+    const int k1 = J > 0 ? (k + J + 1) / 2 : k + J, k2 = k + J - k1;
     const float P1 = ldexpf(1.0f, k1), P2 = ldexpf(1.0f, k2), s1 = ldexpf(s, k + J); /* exact */
     const float r = hr((float)(1.0 / (double)s1));
     for (unsigned vb = 0; vb < 0x7c00u; ++vb) {
