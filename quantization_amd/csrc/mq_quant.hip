@@ -720,18 +720,11 @@ __device__ __forceinline__ void pk_div_params(SegP& sp, int k_base = MQ_PK_OWN) 
   const int k = sp.pk_shared ? k_base : k_own;
   sp.pk_k = k;
   const float s1 = __builtin_ldexpf(sp.sf, k);
-  // (the packed conversion with one source in both places rounds like the scalar one, to nearest even, and leaves
-  //  the value in both halves: one instruction where a conversion and a duplication were two)
-  auto both = [](float x) __attribute__((always_inline)) {
-    uint32_t r;
-    asm("v_cvt_pk_f16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return r;
-  };
-  sp.pk_p = both(__builtin_ldexpf(1.0f, k));  // (k <= 15 is the caller's test: s >= 2^-15)
-  sp.pk_s = both(s1);
+  sp.pk_p = dup16(h_bits((half_t)__builtin_ldexpf(1.0f, k)));  // (k <= 15 is the caller's test: s >= 2^-15)
+  sp.pk_s = dup16(h_bits((half_t)s1));
   // v_rcp_f32 is within 1 ulp of 1 / s'; for each of the 1024 values of s' every float32 within 2 ulp of 1 / s'
   // rounds to the same float16 (same test program)
-  sp.pk_r = both(__builtin_amdgcn_rcpf(s1));
+  sp.pk_r = dup16(h_bits((half_t)__builtin_amdgcn_rcpf(s1)));
 }
 __device__ __forceinline__ h16x2 div_pk16_pre(uint32_t v1w, const SegP& sp) {  // v1w: v P, both halves
   const h16x2 v1 = as_h2(v1w);
