@@ -129,11 +129,14 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
     }
     SegP sp0;
     // integer formats: the row's power of two serves every grouping of the row (pk_div_params): v P once per word
+    // (rows of up to two runs per lane: with more, the 16 registers of the scaled copy cost a wave of occupancy --
+    //  170 VGPRs for NR = 4, WPR = 4 -- and the launch was up to 27 % slower)
+    constexpr bool SHARE = !MQ_IS_LUT(FMT) && NR <= 2;
     int kb = MQ_PK_OWN;
     if (on0) {
       sp0 = row_params(rowred);
       seen_slow = seen_slow || sp0.slow;
-      if constexpr (!MQ_IS_LUT(FMT)) kb = (sp0.slow || (b.multi_mask & 0x80000000u)) ? MQ_PK_OWN : sp0.pk_k;
+      if constexpr (SHARE) kb = (sp0.slow || (b.multi_mask & 0x80000000u)) ? MQ_PK_OWN : sp0.pk_k;
     }
     const bool share = kb != MQ_PK_OWN;  // (uniform over the row)
     double rs0 = 0.0;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
       const bool valid = whole || run < runs;
       const u32x4* v = &raw[4 * r];
       u32x4 pre[4];
-      if (share) {
+      if (SHARE && share) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256) void k_stats_multi(const QuantBatch b) {
       }
       // one grouping of the run: on the shared words when every lane's segment took the row's power of two
       auto vectors = [&](const SegP& sp, bool lane_ok, double& s, double& ab) __attribute__((always_inline)) {
-        if constexpr (!MQ_IS_LUT(FMT)) {
+        if constexpr (SHARE) {
           if (share && __builtin_amdgcn_ballot_w64(lane_ok && !sp.pk_shared) == 0ull) {
             stats_vectors<FMT, 4, false, true>(p, v, sp, s, ab, nullptr, pre);
             return;
