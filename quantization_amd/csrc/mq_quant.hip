@@ -413,10 +413,22 @@ __device__ __forceinline__ half_t div_qmax(half_t a, const QuantParams& p) {
   }
   return (half_t)(af / p.qmax);
 }
+// v_rcp_f32 is a transcendental instruction: a vector instruction that reads its result needs one wait state in
+// between.  The compiler puts it in front of the instructions it emits itself, but not in front of an inline-asm
+// statement -- and several of the statistics kernels' instructions are inline asm.  The copy below carries the wait
+// state, so whatever reads the reciprocal afterwards reads a settled register.  (Found the hard way: a packed
+// conversion written as asm directly behind a reciprocal gave wrong scales in ONE instantiation of the row kernels,
+// where the scheduler had left nothing between the two.)
+__device__ __forceinline__ float rcp_settled(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  float out;
+  asm("s_nop 0\n\tv_mov_b32 %0, %1" : "=v"(out) : "v"(r));
+  return out;
+}
 __device__ __forceinline__ void finish_params(SegP& sp, half_t s) {
   sp.s = s;
   sp.sf = (float)s;
-  sp.r = __builtin_amdgcn_rcpf(sp.sf);
+  sp.r = rcp_settled(sp.sf);
 }
 
 // h(v / s) for finite v.  q1 rounds to the same float16 as the IEEE quotient v / s for every finite
@@ -720,11 +732,22 @@ __device__ __forceinline__ void pk_div_params(SegP& sp, int k_base = MQ_PK_OWN) 
   const int k = sp.pk_shared ? k_base : k_own;
   sp.pk_k = k;
   const float s1 = __builtin_ldexpf(sp.sf, k);
-  sp.pk_p = dup16(h_bits((half_t)__builtin_ldexpf(1.0f, k)));  // (k <= 15 is the caller's test: s >= 2^-15)
-  sp.pk_s = dup16(h_bits((half_t)s1));
+  // (the packed conversion with one source in both places rounds like the scalar one, to nearest even, and leaves
+  //  the value in both halves: one instruction where a conversion and a duplication were two; the reciprocal's
+  //  carries the wait state a transcendental result needs, see rcp_settled)
+  auto both = [](float x) __attribute__((always_inline)) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+  };
+  sp.pk_p = both(__builtin_ldexpf(1.0f, k));  // (k <= 15 is the caller's test: s >= 2^-15)
+  sp.pk_s = both(s1);
   // v_rcp_f32 is within 1 ulp of 1 / s'; for each of the 1024 values of s' every float32 within 2 ulp of 1 / s'
   // rounds to the same float16 (same test program)
-  sp.pk_r = dup16(h_bits((half_t)__builtin_amdgcn_rcpf(s1)));
+  {
+    const float rf = __builtin_amdgcn_rcpf(s1);
+    asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %1" : "=v"(sp.pk_r) : "v"(rf));
+  }
 }
 __device__ __forceinline__ h16x2 div_pk16_pre(uint32_t v1w, const SegP& sp) {  // v1w: v P, both halves
   const h16x2 v1 = as_h2(v1w);
