@@ -192,6 +192,10 @@ class ModelSweep:
                                 "layer; launches per format and column count, in chunks of layers). achieved counts the bytes the "
                                 "launch moves (each weight once, every list), not once per grouping: the launch is bound by "
                                 "instruction issue, not by HBM")
+        elif self.numpy_order:
+            self.kernel_desc = ("statistics-only fused quantize pass in numpy's summation order (k_np_group3: g = 32 / 64 / 128 "
+                                "from ONE read of a chunk of layers; k_np_row / k_np_rowx: the per-channel pass; both emit the float32 "
+                                "pairwise sums of numpy's 8192-element chunks, the finishing launches add them in order)")
 
     def step(self):
         import torch
