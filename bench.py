@@ -7,9 +7,10 @@
 Headline workload "llama8b" (BASELINE.json configs[3]): all 225 linear weights of Llama-3-8B (random-init bf16,
 15.0 GB), symmetric int8 error statistics per-channel and per-group g = 32 / 64 / 128 -- four passes over the
 model per step -- with the layers SHARDED over the N ranks (greedy longest-processing-time on the element
-count; no weight crosses GPUs).  Per rank a pass is ONE fused launch over all its layers whose segments have one
-length (report.SweepPlan: mq_sweep_run; five launches per step); per step RCCL carries one all-reduce of the per-layer record table
-(distributed.gather_records) and the histogram all-reduces of one model-wide P99 taken jointly over every
+count; no weight crosses GPUs).  Per rank the four groupings of a layer come from ONE read of it (report.SweepPlan:
+mq_sweep_multi_launch over chunks of layers, nine launches per step at N = 1; the one-launch-per-pass form, mq_sweep_run,
+is timed beside it); per step RCCL carries one all-reduce of the per-layer record table
+(distributed.reduce_table) and the histogram all-reduces of one model-wide P99 taken jointly over every
 rank's per-channel MSE lists (distributed.joint_percentile).  "llama70b" (configs[4]) is the same over the 561
 weights of Llama-3-70B (139 GB) with int8 sym / asym, fp8_e4m3, fp8_e3m4 x {per-channel, g = 32 / 64 / 128};
 "tinyllama" (configs[0]) per-channel int8 on fp16 weights.  The total work is fixed as N grows ("strong").
@@ -64,7 +65,7 @@ def parse_args():
     ap.add_argument("--dist", default="normal", choices=["normal", "student_t"])
     ap.add_argument("--numpy-order", action="store_true",
                     help="model sweeps: every mean in numpy's summation order (mse_tensor / mse_rep / mse_p99 in the "
-                         "reference's bits); a correctness mode, an order of magnitude slower")
+                         "reference's bits); about 1.6 x the default step")
     ap.add_argument("--dump-table", metavar="PATH", default=None,
                     help="model sweeps: rank 0 saves the last step's record table and model-wide P99 (numpy .npz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
