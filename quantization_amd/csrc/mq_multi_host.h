@@ -112,7 +112,9 @@ static int sweep_multi_launch(const void* table_dev, int32_t count, int64_t cols
   b.multi_count = count;
   // (measurements: MQ_MULTI_NOSHARE=1 keeps every grouping on its own power of two, see pk_div_params)
   static const bool noshare = getenv("MQ_MULTI_NOSHARE") && atoi(getenv("MQ_MULTI_NOSHARE")) != 0;
-  b.multi_mask = mask | (noshare ? 0x80000000u : 0u);
+  // (MQ_MULTI_NOSKIP=1: waves compute the empty runs of rows that do not fill the kernel's grid)
+  static const bool noskip = getenv("MQ_MULTI_NOSKIP") && atoi(getenv("MQ_MULTI_NOSKIP")) != 0;
+  b.multi_mask = mask | (noshare ? 0x80000000u : 0u) | (noskip ? 0x40000000u : 0u);
   b.sweep_partials = static_cast<double*>(workspace);
   hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
   if (prof_on) {

@@ -18,7 +18,9 @@ def run(budget, seed):
     t0, n = time.time(), 0
     while time.time() - t0 < budget:
         nshapes = int(rng.integers(1, 4))
-        shapes = [(int(rng.integers(1, 300)), 128 * int(rng.integers(1, 24))) for _ in range(nshapes)]
+        # (one shape in four is wide: rows of more than 8192 elements are held by a workgroup, not by a wave)
+        shapes = [(int(rng.integers(1, 40)), 128 * int(rng.integers(65, 257))) if rng.integers(4) == 0 else
+                  (int(rng.integers(1, 300)), 128 * int(rng.integers(1, 24))) for _ in range(nshapes)]
         layers = [shapes[rng.integers(nshapes)] for _ in range(int(rng.integers(1, 40)))]
         dt = [torch.float16, torch.bfloat16][rng.integers(2)]
         scale = float(rng.choice([0.02, 1.0, 1e-3]))
