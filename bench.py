@@ -461,8 +461,8 @@ def timed_run(step, steps, warmup, device, dist, world, reserve):
     wall = time.perf_counter() - t0
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
-        torch.cuda.synchronize()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        from quantization_amd.distributed import all_reduce_
+        all_reduce_(tmax, op=dist.ReduceOp.MAX)
     kern_total_ms, kern_launches = ctypes.c_double(0), ctypes.c_int64(0)
     _lib.check(L.mq_profile_end(ctypes.byref(kern_total_ms), ctypes.byref(kern_launches)))
     return float(tmax.item()), ev0.elapsed_time(ev1), kern_total_ms.value, kern_launches.value
@@ -579,7 +579,9 @@ def main():
     # per-rank shares, for the record
     shares = None
     if sharded:
-        mine = torch.tensor([wl.local_weight_bytes, len(wl.mine)], dtype=torch.int64, device=device)
+        # (device tensors for RCCL, host tensors for the gloo rehearsal)
+        mine = torch.tensor([wl.local_weight_bytes, len(wl.mine)], dtype=torch.int64,
+                            device=device if backend == "nccl" else "cpu")
         allr = [torch.zeros_like(mine) for _ in range(world)]
         if world > 1:
             torch.cuda.synchronize()

@@ -24,13 +24,22 @@ def lpt_partition(sizes: Sequence[int], world: int) -> List[List[int]]:
     return [sorted(p) for p in parts]
 
 
-def _drain_for_host_backend(group=None) -> None:
-    """gloo (the CPU stand-in for RCCL in rehearsals and tests) stages device tensors through pinned host memory
-    on a worker thread; on ROCm that has been seen to wait forever when the device still has queued work, so the
-    calling stream is drained first.  RCCL collectives are enqueued on the stream and need nothing."""
+def all_reduce_(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    """dist.all_reduce of a device tensor, in place.  RCCL ("nccl"): enqueued on the current stream, as it is.
+    Any other backend -- gloo, the CPU stand-in for RCCL in rehearsals and tests -- gets a HOST copy made here:
+    gloo's own staging of device tensors (pinned buffers, a worker thread) has been seen to wait forever on ROCm,
+    with queued work on the device and, intermittently, with two ranks sharing one GPU even after the device was
+    drained.  The device is drained first (every stream), the result is copied back."""
     import torch.distributed as dist
-    if dist.get_backend(group) != "nccl" and torch.cuda.is_available():
-        torch.cuda.synchronize()
+    op = dist.ReduceOp.SUM if op is None else op
+    if dist.get_backend(group) == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, op=op, group=group)
+        return t
+    torch.cuda.synchronize()
+    h = t.cpu()
+    dist.all_reduce(h, op=op, group=group)
+    t.copy_(h)
+    return t
 
 
 def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tensor], n_total: int, width: int,
@@ -43,8 +52,7 @@ def gather_records(local_idx: Sequence[int], local_records: Optional[torch.Tenso
         idx = local_idx if isinstance(local_idx, torch.Tensor) else torch.as_tensor(list(local_idx), device=device)
         table[idx.to(device)] = local_records.to(torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        _drain_for_host_backend(group)
-        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_(table, group=group)
     return table
 
 
@@ -55,8 +63,7 @@ def reduce_table(table: torch.Tensor, group=None) -> torch.Tensor:
     process group: the table as it is."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        _drain_for_host_backend(group)
-        dist.all_reduce(table, op=dist.ReduceOp.SUM, group=group)
+        all_reduce_(table, group=group)
     return table
 
 
@@ -137,8 +144,7 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
     if total is None:
         n = torch.tensor([sum(x.numel() for x in xs)], dtype=torch.int64, device=dev)
         if dist_on:
-            _drain_for_host_backend(group)
-            dist.all_reduce(n, group=group)
+            all_reduce_(n, group=group)
         n = int(n.item())
     else:
         n = int(total)
@@ -172,8 +178,7 @@ def joint_percentile(tensors: Sequence[torch.Tensor], pct: float = 99.0, group=N
             if n >= 1 << 31:
                 raise OverflowError("joint_percentile: 2^31 or more values in one selection across ranks")
             hist = ws[off.value: off.value + 4 * cnt.value].view(torch.int32)
-            _drain_for_host_backend(group)
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_(hist, group=group)
             global _merged_hist_checked
             if not _merged_hist_checked:
                 _merged_hist_checked = True
