@@ -2578,6 +2578,7 @@ static void launch_stats(int scope, int nv, int team_log2, dim3 grid, hipStream_
     }
   } else {
     switch (nv) {
+      case 6: MQ_STATS_ROW(6, 4); break;  // (rows of up to 12288 elements: 11008 fills 22 of 24 wave-vectors, 28 with NV = 7)
       case 7: MQ_STATS_ROW(7, 4); break;
       case 8: MQ_STATS_ROW(8, 4); break;
       case 14: MQ_STATS_ROW(14, 4); break;
@@ -3136,7 +3137,7 @@ static int quantize_launch(const mq_quant_item* items, int32_t count, int32_t w_
       wb = (p.nseg + 3) / 4;
     } else {             // one 256-thread workgroup per row
       scope = SC_STATS_ROWBLK;
-      nv = vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
+      nv = vecs <= 1536 ? 6 : vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
       wb = p.nseg;
     }
     int64_t cap = grid_cap();
@@ -3207,7 +3208,7 @@ static bool sweep_scope(int64_t L, int* scope, int* nv, int* team_log2) {
     *nv = vecs <= 128 ? 2 : vecs <= 256 ? 4 : vecs <= 512 ? 8 : vecs <= 768 ? 12 : 16;
   } else if (vecs <= 4096) {
     *scope = SC_STATS_ROWBLK;
-    *nv = vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
+    *nv = vecs <= 1536 ? 6 : vecs <= 1792 ? 7 : vecs <= 2048 ? 8 : vecs <= 3584 ? 14 : 16;
   } else {
     return false;
   }
