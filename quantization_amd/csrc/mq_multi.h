@@ -200,12 +200,40 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) && NR == 4 && WPR == 4) ? 3 : 
       const uint32_t r1 = red[r];
       const uint32_t r2 = stats_op<FMT>(r1, dpp<DPP_XOR1>(r1));
       const uint32_t r3 = stats_op<FMT>(r2, dpp<DPP_XOR2>(r2));
+      // Formats whose parameters come from the absolute maximum alone: the half of a group that holds the group's
+      // maximum has the parameters -- and so the errors -- it had in the grouping below, bit for bit; only the other
+      // half is quantized again.  Its run (g = 64; its two runs for g = 128) is shared out: the lane that holds it
+      // takes its first two vectors, the lane one (two) over in the half that has nothing to compute its last two.
+      // A run's sum is double(float32 sum of vectors 0, 1) + double(float32 sum of vectors 2, 3) either way, so the
+      // list entries keep their bits; the |error| sums are added in another order (tensor totals, to 1e-6 as rows).
+      // own: this lane's half holds the maximum; prev_*: the run's sums in the grouping below
+      auto half_again = [&](auto ctrl, bool own, const SegP& sp, double prev_s, double prev_ab, double& s, double& ab)
+                            __attribute__((always_inline)) {
+        constexpr int CTRL = decltype(ctrl)::value;
+        u32x4 x[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t theirs = dpp<CTRL>(v[2 + k][i]);
+            x[k][i] = own ? theirs : v[k][i];
+          }
+        double sx, abx;
+        stats_vectors<FMT, 2>(p, x, sp, sx, abx);
+        const double ox = dpp_f64<CTRL>(sx), oab = dpp_f64<CTRL>(abx);
+        s = own ? prev_s : sx + ox;
+        ab = own ? prev_ab : abx + oab;
+      };
+      constexpr bool NEST = FMT != MQ_INT_ASYM;
+      double run_s = 0.0, run_ab = 0.0;  // this lane's run in the grouping below (before the slow / valid mask)
       if (on1) {
         const SegP sp = stats_params<FMT>(r1, p, kb);
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
         vectors(sp, take, s, ab);
+        run_s = s;
+        run_ab = ab;
         s = take ? s : 0.0;
         sse1 += s;
         abs1 += take ? ab : 0.0;
@@ -216,7 +244,10 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) && NR == 4 && WPR == 4) ? 3 : 
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
-        vectors(sp, take, s, ab);
+        if (NEST && on1) half_again(std::integral_constant<int, DPP_XOR1>{}, r1 == r2, sp, run_s, run_ab, s, ab);
+        else vectors(sp, take, s, ab);
+        run_s = s;
+        run_ab = ab;
         s = take ? s : 0.0;
         sse2 += s;
         abs2 += take ? ab : 0.0;
@@ -228,7 +259,8 @@ __global__ __launch_bounds__(256, (MQ_IS_LUT(FMT) && NR == 4 && WPR == 4) ? 3 : 
         const bool take = valid && !sp.slow;
         seen_slow = seen_slow || (valid && sp.slow);
         double s, ab;
-        vectors(sp, take, s, ab);
+        if (NEST && on2) half_again(std::integral_constant<int, DPP_XOR2>{}, r2 == r3, sp, run_s, run_ab, s, ab);
+        else vectors(sp, take, s, ab);
         s = take ? s : 0.0;
         sse3 += s;
         abs3 += take ? ab : 0.0;
