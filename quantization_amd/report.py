@@ -319,7 +319,7 @@ class SweepPlan:
         self.multi_ws_bytes = 0
         self.side_ws_bytes = 0
         self.select_beside = os.environ.get("MQ_SWEEP_SELECT_BESIDE", "1") != "0"   # (measurements either way)
-        self.beside_bytes = int(os.environ.get("MQ_SWEEP_BESIDE_MB", "512")) << 20
+        self.beside_bytes = int(os.environ.get("MQ_SWEEP_BESIDE_MB", "256")) << 20
         self.fin_ws_bytes = 1 << 16
         self.fin_ws = None
         # numpy order: every finishing call writes its tensors' mse_rep / mse_tensor into a run of these two buffers;
