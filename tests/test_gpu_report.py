@@ -580,6 +580,41 @@ def test_fused_groupings_equal_separate_passes(dt):
     assert np.array_equal(a, a2, equal_nan=True)
 
 
+@pytest.mark.parametrize("fmt,bits", [("int8", 8), ("int4", 4), ("fp8_e4m3", 8), ("fp4", 4)])
+def test_fused_groupings_with_equal_maxima_and_partial_families(fmt, bits):
+    """The fused launch quantizes only the half of a group that does NOT hold the group's maximum again (formats scaled
+    by the absolute maximum).  Here the maxima tie -- every run of 32, or every other one, or one run in four holds the
+    same largest magnitude, with either sign -- and the families leave groupings out (64 + 128 without 32, 32 + 128
+    without 64, rows + 64), on rows of one wave and of a workgroup: every list entry against the one-launch-per-pass
+    kernels, bit for bit for the integer formats."""
+    from quantization_amd import report
+    g = torch.Generator().manual_seed(11)
+    ws = []
+    for k, (r, c) in enumerate([(24, 4096), (9, 14336), (16, 1024), (5, 9216), (12, 2048), (7, 8192)]):
+        w = torch.randn(r, c, generator=g) * 0.02
+        step = (32, 64, 128)[k % 3]
+        sign = torch.where(torch.rand(r, c // step, generator=g) < 0.5, -1.0, 1.0)
+        w[:, (k * 5) % 32::step] = 0.25 * sign            # the tied maxima (0.25 is exact in float16 / bfloat16)
+        if k % 2:
+            w[1, :] = 0.0                                  # a zero row: off the fast path
+            w[2, 64:128] = 0.0                             # a zero group of 64 inside a live row
+        ws.append(w.to(torch.bfloat16 if k % 2 else torch.float16).cuda())
+    for sizes in ([64, 128], [32, 128], [None, 64], [None, 32, 64, 128], [32, 64]):
+        passes = [(fmt, bits, gs) for gs in sizes]
+        fused = report.SweepPlan(ws, passes, fuse_groupings=True)
+        plain = report.SweepPlan(ws, passes, fuse_groupings=False)
+        assert "multisweep" in [la[0] for ps in fused.plan for la in ps["launches"]]
+        a, b = fused.run().cpu().numpy(), plain.run().cpu().numpy()
+        for k, ps in enumerate(passes):
+            for i in range(len(ws)):
+                x, y = fused.lists(k)[i], plain.lists(k)[i]
+                if fmt.startswith("int") and ps[2] is not None:
+                    assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (ps, tuple(ws[i].shape))
+                else:
+                    assert torch.allclose(x.double(), y.double(), rtol=1e-6, atol=0, equal_nan=True), (ps, tuple(ws[i].shape))
+            assert np.allclose(a[k, :, :5], b[k, :, :5], rtol=3e-6, atol=0, equal_nan=True), ps
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_percentiles_beside_a_busy_chip_equal_the_plain_call(dtype):
     """mq_percentile_multi_beside (256-thread workgroups, for calls that run next to a chip-filling kernel) against
